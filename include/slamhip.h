@@ -1,0 +1,179 @@
+/*
+ * slamhip.h — C ABI of libslamhip.so, the MI355X (gfx950) drop-in for the one
+ * data-parallel hot path of ViV99/slam-experiments.
+ *
+ * The reference is pure Python; its "FFI" for this path is the call into the
+ * cv2 / g2o wheels.  Each entry point below names the reference call site it
+ * replaces (file:line in /root/reference):
+ *
+ *   slam_bf_knn2_u256      cv2.BFMatcher(NORM_HAMMING).match / knnMatch(k=2)
+ *                          behind BruteForceFeatureMatcher.match
+ *                          (feature_matchers.py:33-39), called from
+ *                          Frontend._match_features (frontend.py:181-187)
+ *   slam_bf_match_filter   the post-match filter of feature_matchers.py:41-43
+ *                          (+ Lowe ratio / crossCheck, OpenCV semantics)
+ *   slam_reproj_rj_f64     EdgeProjectionPoseOnly.compute_error /
+ *                          linearize_oplus (frontend.py:272-291), driven by
+ *                          Frontend._correct_current_pose (frontend.py:298-393)
+ *   slam_comm_*            no reference counterpart (the reference is single
+ *                          process); RCCL all-gather of per-shard top-2 rows
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative slam_status; the
+ *     message of the last failure on the calling thread is slam_last_error().
+ *   - no exceptions cross the boundary; no torch / numpy types in signatures.
+ *   - pointers named d_* are DEVICE pointers obtained from slam_malloc on the
+ *     same context; pointers named h_* are host pointers owned by the caller
+ *     and only read/written during the call.
+ *   - a slam_ctx owns one HIP device + one HIP stream; calls on one ctx are
+ *     stream-ordered, different ctxs are independent (one per thread / GPU).
+ *   - empty inputs are not errors: N == 0 is a no-op; M == 0 yields idx = -1,
+ *     dist = INT32_MAX (OpenCV's "no neighbour").
+ */
+#ifndef SLAMHIP_H
+#define SLAMHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct slam_ctx slam_ctx;
+
+#define SLAM_API __attribute__((visibility("default")))
+
+enum slam_status {
+    SLAM_OK = 0,
+    SLAM_ERR_INVALID = -1,   /* bad argument (null pointer, negative size, limit exceeded) */
+    SLAM_ERR_HIP = -2,       /* a HIP runtime call failed */
+    SLAM_ERR_NO_DEVICE = -3, /* no gfx950 device visible */
+    SLAM_ERR_RCCL = -4,      /* RCCL missing or a collective failed */
+    SLAM_ERR_STATE = -5      /* call made in the wrong state (e.g. comm not initialised) */
+};
+
+/* descriptor geometry: 256-bit ORB descriptors, one row = 32 bytes
+ * (Frame.get_descriptors -> (n,32) uint8, primitives.py:200-205) */
+#define SLAM_DESC_BYTES 32
+/* top-2 keys pack (distance << 23 | index): one launch covers at most 2^23
+ * train rows; larger train sets are looped by the library */
+#define SLAM_MAX_TRAIN_PER_PASS (1 << 23)
+#define SLAM_NO_MATCH_IDX (-1)
+#define SLAM_NO_MATCH_DIST 2147483647
+
+/* ---- library / context ------------------------------------------------- */
+SLAM_API const char* slam_last_error(void);
+SLAM_API const char* slam_version(void);
+SLAM_API int slam_device_count(int* count);
+SLAM_API int slam_ctx_create(int device, slam_ctx** out);
+SLAM_API int slam_ctx_destroy(slam_ctx* ctx);
+SLAM_API int slam_ctx_device(slam_ctx* ctx, int* device);
+SLAM_API int slam_sync(slam_ctx* ctx);
+
+/* ---- device memory (caller keeps the pointer, library tracks it) ------- */
+SLAM_API int slam_malloc(slam_ctx* ctx, uint64_t bytes, void** d_ptr);
+SLAM_API int slam_free(slam_ctx* ctx, void* d_ptr);
+SLAM_API int slam_memset(slam_ctx* ctx, void* d_ptr, int value, uint64_t bytes);
+SLAM_API int slam_upload(slam_ctx* ctx, void* d_dst, const void* h_src, uint64_t bytes);
+SLAM_API int slam_download(slam_ctx* ctx, void* h_dst, const void* d_src, uint64_t bytes);
+
+/* ---- stream timers (HIP events on the ctx stream) ----------------------- */
+SLAM_API int slam_timer_start(slam_ctx* ctx);
+SLAM_API int slam_timer_stop(slam_ctx* ctx, float* ms); /* synchronises */
+/* when enabled, every slam_bf_knn2_u256 / slam_reproj_rj_f64 brackets its
+ * dominant kernel with events; slam_prof_read returns count and total ms */
+SLAM_API int slam_prof_enable(slam_ctx* ctx, int on);
+SLAM_API int slam_prof_read(slam_ctx* ctx, int64_t* launches, double* total_ms); /* synchronises, then resets */
+
+/* ---- hot path 1: brute-force Hamming top-2 ------------------------------ */
+/* For each of N query rows, the two nearest of M train rows under
+ * popcount(q xor t), ordered by (distance asc, train index asc) — the order
+ * cv2.BFMatcher.knnMatch(k=2) produces.  d_idx/d_dist are int32 [N,2];
+ * column 0 is the 1-NN (what feature_matchers.py:39 returns), column 1 the
+ * 2-NN; missing neighbours are (-1, INT32_MAX).  train_base is added to
+ * every reported index (used by shards). */
+SLAM_API int slam_bf_knn2_u256(slam_ctx* ctx, const void* d_query, int64_t N,
+                      const void* d_train, int64_t M, int64_t train_base,
+                      int32_t* d_idx, int32_t* d_dist);
+
+/* Merge G partial top-2 tables ([G][N][2] idx and dist, already holding
+ * global indices) into one, by (dist, idx) order.  Used by train-sharded
+ * runs and by passes over train sets larger than 2^23 rows. */
+SLAM_API int slam_bf_merge_top2(slam_ctx* ctx, const int32_t* d_idx_parts,
+                       const int32_t* d_dist_parts, int64_t G, int64_t N,
+                       int32_t* d_idx, int32_t* d_dist);
+
+/* Host-pointer convenience (uploads, runs, downloads; PCIe inclusive). */
+SLAM_API int slam_bf_knn2_u256_host(slam_ctx* ctx, const uint8_t* h_query, int64_t N,
+                           const uint8_t* h_train, int64_t M,
+                           int32_t* h_idx, int32_t* h_dist);
+
+/* Tuning override for experiments: R = queries per lane (0 = heuristic; 1, 2,
+ * 4 or 8), blocks_per_cu = grid size target (0 = default 4).  Process-wide. */
+SLAM_API int slam_bf_set_tuning(int R, int blocks_per_cu);
+
+/* Post-match selection on the device (feature_matchers.py:41-43 and the
+ * OpenCV knn / ratio semantics).  Input: the [N,2] tables above.
+ *   mode 0: 1-NN of every query that has one                 (bf.match, feature_matchers.py:39,44)
+ *   mode 1: 1-NN kept iff dist < max(2*min_dist, param)      (feature_matchers.py:42-43, strict <)
+ *   mode 2: Lowe ratio: kept iff dist0 < param * dist1       (strict; needs 2 neighbours)
+ * d_keep is uint8 [N]; *h_count receives the number kept; *h_min_dist the
+ * minimum 1-NN distance over all queries (INT32_MAX if none).  Synchronises. */
+SLAM_API int slam_bf_match_filter(slam_ctx* ctx, const int32_t* d_idx, const int32_t* d_dist,
+                         int64_t N, int mode, double param,
+                         uint8_t* d_keep, int64_t* h_count, int32_t* h_min_dist);
+
+/* crossCheck=True selection (cv2.BFMatcher(normType, crossCheck=True).match):
+ * given the REVERSE search (every train row's nearest query, [M,2] tables from
+ * slam_bf_knn2_u256(train as query, query as train)), each query q receives the
+ * train row t with the smallest (dist, t) among rows whose nearest query is q;
+ * queries chosen by no train row get idx -1.  d_out_idx / d_out_dist are
+ * int32 [N].  Synchronises. */
+SLAM_API int slam_bf_cross_check(slam_ctx* ctx, const int32_t* d_rev_idx, const int32_t* d_rev_dist,
+                        int64_t M, int64_t N, int32_t* d_out_idx, int32_t* d_out_dist,
+                        int64_t* h_count);
+
+/* ---- hot path 2: reprojection residual + Jacobians (f64) ---------------- */
+/* Per observation o with pose k = d_obs_pose[o], point l = d_obs_point[o]:
+ *   p_c = R_k p_l + t_k                      (T * pos3d,  frontend.py:275)
+ *   e   = meas_o - (fx X/Z + cx, fy Y/Z + cy)            (frontend.py:275-277)
+ *   Zinv = 1/(Z + 1e-18); J_pose = 2x6, rotation columns first
+ *                                                        (frontend.py:284-291)
+ *   J_point = -dproj/dp_c * R_k (2x3)  — extension, not in the reference
+ * d_poses: [K,12] f64 = row-major R (9) then t (3), i.e. the top 3x4 of Tcw
+ * flattened as [R|t] rows: (r00 r01 r02 tx r10 r11 r12 ty r20 r21 r22 tz).
+ * d_points [L,3], d_meas [O,2], outputs d_e [O,2], d_Jpose [O,12] (row-major
+ * 2x6), d_Jpoint [O,6] (row-major 2x3) or NULL to skip it. */
+SLAM_API int slam_reproj_rj_f64(slam_ctx* ctx, const double* d_poses, int64_t K,
+                       const double* d_points, int64_t L,
+                       const int32_t* d_obs_pose, const int32_t* d_obs_point,
+                       const double* d_meas, int64_t O,
+                       double fx, double fy, double cx, double cy,
+                       double* d_e, double* d_Jpose, double* d_Jpoint);
+
+/* Pose-only normal equations for one pose (frontend.py:298-365 inner build):
+ * H = sum w J^T J (6x6, row-major), b = sum w J^T e (6), chi2[o] = e.e,
+ * w = Huber weight with delta (delta <= 0: w = 1); observations whose
+ * d_active[o] == 0 are skipped (g2o "level 1" edges, frontend.py:372-377).
+ * d_pose [12] as above; outputs d_H [36], d_b [6], d_chi2 [O] on device. */
+SLAM_API int slam_pose_normal_eq_f64(slam_ctx* ctx, const double* d_pose,
+                            const double* d_points, const double* d_meas,
+                            const uint8_t* d_active, int64_t O,
+                            double fx, double fy, double cx, double cy,
+                            double huber_delta,
+                            double* d_H, double* d_b, double* d_chi2);
+
+/* ---- multi-GPU: RCCL all-gather of per-shard result rows ---------------- */
+#define SLAM_COMM_ID_BYTES 128
+SLAM_API int slam_comm_unique_id(void* h_id /*[128]*/);
+SLAM_API int slam_comm_init(slam_ctx* ctx, int nranks, int rank, const void* h_id);
+SLAM_API int slam_comm_destroy(slam_ctx* ctx);
+/* every rank contributes bytes_per_rank bytes; d_recv holds nranks*bytes_per_rank.
+ * in-place allowed when d_send == d_recv + rank*bytes_per_rank. */
+SLAM_API int slam_comm_allgather(slam_ctx* ctx, const void* d_send, void* d_recv, uint64_t bytes_per_rank);
+SLAM_API int slam_comm_broadcast(slam_ctx* ctx, void* d_buf, uint64_t bytes, int root);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLAMHIP_H */

@@ -1,0 +1,178 @@
+/*
+ * bf_hamming_oracle.c — CPU restatement of the reference's descriptor-matching
+ * path.  TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg; never by the product path.
+ *
+ * PARITY UNPINNED: the reference (feature_matchers.py:33-44) delegates to
+ * cv2.BFMatcher, i.e. opencv-python 4.9.0.80 (poetry.lock:1798-1799), which is
+ * not vendored under /root/reference and not installable here; the reference
+ * has no tests or golden vectors.  This file restates OpenCV's published
+ * algorithm and is pinned only by the hand-derived known-answer vectors in
+ * tests/golden/ (SURVEY.md §8c).
+ *
+ * What is restated, and from where:
+ *   - BruteForceFeatureMatcher.match(source, query, dist_threshold)
+ *       feature_matchers.py:36-44: bf.match(query, source), then the optional
+ *       "distance < max(2*min_dist, dist_threshold)" filter (strict <).
+ *   - cv2.BFMatcher.match/knnMatch(normType=NORM_HAMMING, crossCheck=False)
+ *       OpenCV 4.9.0 modules/features2d/src/matchers.cpp (BFMatcher::knnMatchImpl)
+ *       and modules/core/src/batch_distance.cpp (BatchDistInvoker): distances as
+ *       int32, K best kept per query by insertion while scanning train rows in
+ *       ascending order: enter iff d < dist[K-1] (strict), shift while
+ *       dist[k] > d (strict).  Hence order (distance asc, train index asc), ties
+ *       to the lowest index; dist initialised INT_MAX, idx -1.
+ *   - multi-image train sets: images scanned in order, index encoded
+ *       imgIdx << 18 | trainIdx (IMGIDX_SHIFT = 18 in matchers.cpp).
+ *   - crossCheck=True: batch_distance.cpp crosscheck branch (K == 1): reverse
+ *       1-NN per train row, then for train rows in ascending order
+ *       "if d < dist[q]: dist[q] = d, idx[q] = t".
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <limits.h>
+
+#define DESC_BYTES 32
+#define IMGIDX_SHIFT 18
+#define IMGIDX_ONE (1 << IMGIDX_SHIFT)
+
+/* normHamming over one 256-bit row (OpenCV hal::normHamming) */
+static inline int hamming256(const uint8_t* a, const uint8_t* b) {
+    uint64_t x[4], y[4];
+    memcpy(x, a, 32);
+    memcpy(y, b, 32);
+    return __builtin_popcountll(x[0] ^ y[0]) + __builtin_popcountll(x[1] ^ y[1]) +
+           __builtin_popcountll(x[2] ^ y[2]) + __builtin_popcountll(x[3] ^ y[3]);
+}
+
+/* BatchDistInvoker K-best insertion for one query row against rows
+ * [0, M) of one train image; `update` is added to the stored index. */
+static void knn_insert_row(const uint8_t* q, const uint8_t* t, int64_t M, int K, int update, int* idx, int* dist) {
+    for (int64_t j = 0; j < M; j++) {
+        const int d = hamming256(q, t + j * DESC_BYTES);
+        if (d < dist[K - 1]) {
+            int k;
+            for (k = K - 2; k >= 0 && dist[k] > d; k--) {
+                idx[k + 1] = idx[k];
+                dist[k + 1] = dist[k];
+            }
+            idx[k + 1] = (int)j + update;
+            dist[k + 1] = d;
+        }
+    }
+}
+
+/* knnMatch(query, train, k=K) as raw tables: idx/dist are int32 [N,K], missing
+ * neighbours are (-1, INT_MAX).  Threads split the query rows (OpenCV uses
+ * parallel_for_ over query rows the same way). */
+int oracle_bf_knn_u256(const uint8_t* q, int64_t N, const uint8_t* t, int64_t M, int K, int32_t* idx,
+                       int32_t* dist, int threads) {
+    if (K < 1 || N < 0 || M < 0) return -1;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(threads > 0 ? threads : 1)
+#endif
+    for (int64_t i = 0; i < N; i++) {
+        int* ip = idx + i * K;
+        int* dp = dist + i * K;
+        for (int k = 0; k < K; k++) { ip[k] = -1; dp[k] = INT_MAX; }
+        knn_insert_row(q + i * DESC_BYTES, t, M, K, 0, ip, dp);
+    }
+    return 0;
+}
+
+/* knnMatch against a collection of train images (BFMatcher.add([...])): rows
+ * of all images are concatenated in `t`; img_rows[c] gives each image's row
+ * count.  Stored index = imgIdx << 18 | trainIdx, as OpenCV encodes it. */
+int oracle_bf_knn_multi_u256(const uint8_t* q, int64_t N, const uint8_t* t, const int64_t* img_rows, int n_img,
+                             int K, int32_t* idx, int32_t* dist, int threads) {
+    if (K < 1 || N < 0 || n_img < 0) return -1;
+    for (int c = 0; c < n_img; c++)
+        if (img_rows[c] >= IMGIDX_ONE) return -2; /* CV_Assert(trainDescCollection[iIdx].rows < IMGIDX_ONE) */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(threads > 0 ? threads : 1)
+#endif
+    for (int64_t i = 0; i < N; i++) {
+        int* ip = idx + i * K;
+        int* dp = dist + i * K;
+        for (int k = 0; k < K; k++) { ip[k] = -1; dp[k] = INT_MAX; }
+        const uint8_t* tp = t;
+        int update = 0;
+        for (int c = 0; c < n_img; c++) {
+            knn_insert_row(q + i * DESC_BYTES, tp, img_rows[c], K, update, ip, dp);
+            tp += img_rows[c] * DESC_BYTES;
+            update += IMGIDX_ONE;
+        }
+    }
+    return 0;
+}
+
+/* feature_matchers.py:39-44 on top of a [N,K] table (K >= 1): out arrays get one
+ * entry per returned DMatch (queryIdx, trainIdx, distance as float), in
+ * ascending queryIdx.  dist_threshold <= 0 or NaN-free "falsy" (0.0) means
+ * "no filter", as `if dist_threshold and ...` does.  Returns the match count. */
+int64_t oracle_bf_match(const int32_t* idx, const int32_t* dist, int64_t N, int K, double dist_threshold,
+                        int has_threshold, int32_t* out_query, int32_t* out_train, float* out_dist) {
+    int64_t n = 0;
+    /* bf.match(): one DMatch per query that has a neighbour */
+    for (int64_t i = 0; i < N; i++) {
+        if (idx[i * K] < 0) continue;
+        out_query[n] = (int32_t)i;
+        out_train[n] = idx[i * K];
+        out_dist[n] = (float)dist[i * K];
+        n++;
+    }
+    if (has_threshold && dist_threshold != 0.0 && n != 0) {
+        float min_dist = out_dist[0];
+        for (int64_t i = 1; i < n; i++)
+            if (out_dist[i] < min_dist) min_dist = out_dist[i];
+        const double lim = 2.0 * (double)min_dist > dist_threshold ? 2.0 * (double)min_dist : dist_threshold;
+        int64_t m = 0;
+        for (int64_t i = 0; i < n; i++) {
+            if ((double)out_dist[i] < lim) {
+                out_query[m] = out_query[i];
+                out_train[m] = out_train[i];
+                out_dist[m] = out_dist[i];
+                m++;
+            }
+        }
+        n = m;
+    }
+    return n;
+}
+
+/* Lowe ratio on a [N,2] table: keep[i] = has two neighbours && d0 < ratio * d1
+ * (the usual `m.distance < ratio * n.distance` idiom on float32 distances). */
+int64_t oracle_bf_ratio_test(const int32_t* idx, const int32_t* dist, int64_t N, double ratio, uint8_t* keep) {
+    int64_t n = 0;
+    for (int64_t i = 0; i < N; i++) {
+        const int k = idx[2 * i] >= 0 && idx[2 * i + 1] >= 0 &&
+                      (double)(float)dist[2 * i] < ratio * (double)(float)dist[2 * i + 1];
+        keep[i] = (uint8_t)k;
+        n += k;
+    }
+    return n;
+}
+
+/* crossCheck=True match(query, train): out_idx/out_dist int32 [N], -1 / INT_MAX
+ * where the query is chosen by no train row. */
+int oracle_bf_cross_check_u256(const uint8_t* q, int64_t N, const uint8_t* t, int64_t M, int32_t* out_idx,
+                               int32_t* out_dist, int threads) {
+    int32_t* tidx = (int32_t*)malloc((size_t)(M > 0 ? M : 1) * sizeof(int32_t));
+    int32_t* tdist = (int32_t*)malloc((size_t)(M > 0 ? M : 1) * sizeof(int32_t));
+    if (!tidx || !tdist) { free(tidx); free(tdist); return -1; }
+    /* batchDistance(src2, src1, tdist, tidx, K=1): every train row's nearest query */
+    oracle_bf_knn_u256(t, M, q, N, 1, tidx, tdist, threads);
+    for (int64_t i = 0; i < N; i++) { out_idx[i] = -1; out_dist[i] = INT_MAX; }
+    for (int64_t i = 0; i < M; i++) {
+        const int qi = tidx[i];
+        if (qi < 0) continue;
+        const int d = tdist[i], d0 = out_dist[qi];
+        if (d < d0) {
+            out_dist[qi] = d;
+            out_idx[qi] = (int32_t)i;
+        }
+    }
+    free(tidx);
+    free(tdist);
+    return 0;
+}

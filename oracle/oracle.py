@@ -1,0 +1,269 @@
+"""CPU oracle for the descriptor-matching / reprojection hot path.
+
+TEST INFRASTRUCTURE ONLY.  Only ``tests/``, ``__graft_entry__.smoke()`` and
+``bench.py``'s ``cpu_baseline`` leg may import this module; the product path
+(``slam-experiments_amd/``) never does and fails loudly without its HIP library.
+
+PARITY UNPINNED: the reference delegates this path to cv2
+(opencv-python 4.9.0.80), g2o-python 0.0.12 and jaxlie, none of which is
+installed or installable here, and ships no tests or golden vectors.  The
+oracle is therefore a restatement of the published algorithms, pinned by the
+hand-derived known-answer vectors under ``tests/golden/``.
+
+Two independent restatements live here so they can check each other:
+
+* ``*_c``  — ctypes bindings of ``liboracle.so`` (``bf_hamming_oracle.c``,
+  ``reproj_oracle.c``): OpenCV's K-best insertion loop, line by line.
+* ``*_np`` — numpy: full distance matrix + stable lexicographic sort, and the
+  reference's residual/Jacobian text (``frontend.py:272-291``) with numpy
+  matrices exactly as the Python callbacks compute them.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+_lib = None
+
+NO_IDX = -1
+NO_DIST = 2**31 - 1
+IMGIDX_SHIFT = 18  # OpenCV matchers.cpp: index = imgIdx << 18 | trainIdx
+
+
+def build(force: bool = False) -> str:
+    """Compile liboracle.so with gcc (used by __graft_entry__.build())."""
+    srcs = [os.path.join(_HERE, f) for f in ("bf_hamming_oracle.c", "reproj_oracle.c")]
+    stale = force or not os.path.exists(_LIB_PATH) or any(
+        os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs
+    )
+    if stale:
+        subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s", "all"])
+    return _LIB_PATH
+
+
+def _load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        build()
+    lib = ctypes.CDLL(_LIB_PATH)
+    i64, i32, vp, dbl = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_double
+    lib.oracle_bf_knn_u256.argtypes = [vp, i64, vp, i64, i32, vp, vp, i32]
+    lib.oracle_bf_knn_u256.restype = i32
+    lib.oracle_bf_knn_multi_u256.argtypes = [vp, i64, vp, vp, i32, i32, vp, vp, i32]
+    lib.oracle_bf_knn_multi_u256.restype = i32
+    lib.oracle_bf_match.argtypes = [vp, vp, i64, i32, dbl, i32, vp, vp, vp]
+    lib.oracle_bf_match.restype = i64
+    lib.oracle_bf_ratio_test.argtypes = [vp, vp, i64, dbl, vp]
+    lib.oracle_bf_ratio_test.restype = i64
+    lib.oracle_bf_cross_check_u256.argtypes = [vp, i64, vp, i64, vp, vp, i32]
+    lib.oracle_bf_cross_check_u256.restype = i32
+    lib.oracle_reproj_rj_f64.argtypes = [vp, i64, vp, i64, vp, vp, vp, i64, dbl, dbl, dbl, dbl, vp, vp, vp, i32]
+    lib.oracle_reproj_rj_f64.restype = i32
+    lib.oracle_pose_normal_eq_f64.argtypes = [vp, vp, vp, vp, i64, dbl, dbl, dbl, dbl, dbl, vp, vp, vp]
+    lib.oracle_pose_normal_eq_f64.restype = i32
+    _lib = lib
+    return lib
+
+
+def _desc(a: np.ndarray) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    if a.ndim != 2 or a.shape[1] != 32:
+        a = a.reshape(-1, 32)
+    return a
+
+
+def _p(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+# --------------------------------------------------------------------------
+# matching: C restatement
+# --------------------------------------------------------------------------
+def bf_knn_c(query: np.ndarray, train: np.ndarray, k: int = 2, threads: int = 1) -> Tuple[np.ndarray, np.ndarray]:
+    """cv2.BFMatcher(NORM_HAMMING).knnMatch(query, train, k) as (idx, dist) int32 [N,k]."""
+    q, t = _desc(query), _desc(train)
+    idx = np.empty((q.shape[0], k), np.int32)
+    dist = np.empty((q.shape[0], k), np.int32)
+    rc = _load().oracle_bf_knn_u256(_p(q), q.shape[0], _p(t), t.shape[0], k, _p(idx), _p(dist), threads)
+    assert rc == 0
+    return idx, dist
+
+
+def bf_knn_multi_c(query: np.ndarray, train_images: Sequence[np.ndarray], k: int = 2, threads: int = 1):
+    """knnMatch against BFMatcher.add([...]) collections; returns (imgIdx, trainIdx, dist) [N,k]."""
+    q = _desc(query)
+    imgs = [_desc(t) for t in train_images]
+    rows = np.array([t.shape[0] for t in imgs], np.int64)
+    cat = np.concatenate(imgs, 0) if imgs else np.zeros((0, 32), np.uint8)
+    idx = np.empty((q.shape[0], k), np.int32)
+    dist = np.empty((q.shape[0], k), np.int32)
+    rc = _load().oracle_bf_knn_multi_u256(_p(q), q.shape[0], _p(cat), _p(rows), len(imgs), k, _p(idx), _p(dist), threads)
+    assert rc == 0, rc
+    img = np.where(idx >= 0, idx >> IMGIDX_SHIFT, -1).astype(np.int32)
+    tr = np.where(idx >= 0, idx & ((1 << IMGIDX_SHIFT) - 1), -1).astype(np.int32)
+    return img, tr, dist
+
+
+def bf_match_c(source: np.ndarray, query: np.ndarray, dist_threshold: Optional[float] = None, threads: int = 1):
+    """BruteForceFeatureMatcher.match(source, query, dist_threshold) (feature_matchers.py:36-44).
+
+    Returns (queryIdx, trainIdx, distance float32) arrays, one entry per DMatch."""
+    idx, dist = bf_knn_c(query, source, 1, threads)
+    n = idx.shape[0]
+    oq = np.empty(n, np.int32)
+    ot = np.empty(n, np.int32)
+    od = np.empty(n, np.float32)
+    has = dist_threshold is not None
+    m = _load().oracle_bf_match(_p(idx), _p(dist), n, 1, float(dist_threshold or 0.0), int(has), _p(oq), _p(ot), _p(od))
+    return oq[:m].copy(), ot[:m].copy(), od[:m].copy()
+
+
+def bf_ratio_c(idx: np.ndarray, dist: np.ndarray, ratio: float) -> np.ndarray:
+    idx = np.ascontiguousarray(idx, np.int32)
+    dist = np.ascontiguousarray(dist, np.int32)
+    keep = np.empty(idx.shape[0], np.uint8)
+    _load().oracle_bf_ratio_test(_p(idx), _p(dist), idx.shape[0], float(ratio), _p(keep))
+    return keep.astype(bool)
+
+
+def bf_cross_check_c(query: np.ndarray, train: np.ndarray, threads: int = 1):
+    q, t = _desc(query), _desc(train)
+    oi = np.empty(q.shape[0], np.int32)
+    od = np.empty(q.shape[0], np.int32)
+    rc = _load().oracle_bf_cross_check_u256(_p(q), q.shape[0], _p(t), t.shape[0], _p(oi), _p(od), threads)
+    assert rc == 0
+    return oi, od
+
+
+# --------------------------------------------------------------------------
+# matching: numpy restatement (independent of the C loop)
+# --------------------------------------------------------------------------
+def hamming_matrix_np(query: np.ndarray, train: np.ndarray) -> np.ndarray:
+    q, t = _desc(query), _desc(train)
+    out = np.empty((q.shape[0], t.shape[0]), np.int32)
+    step = max(1, (1 << 24) // max(1, t.shape[0]))  # ~512 MiB of xor temporaries at most
+    for a in range(0, q.shape[0], step):
+        x = q[a:a + step, None, :] ^ t[None, :, :]
+        out[a:a + step] = np.bitwise_count(x).sum(-1, dtype=np.int32)
+    return out
+
+
+def bf_knn_np(query: np.ndarray, train: np.ndarray, k: int = 2) -> Tuple[np.ndarray, np.ndarray]:
+    """(distance asc, train index asc) top-k via a stable sort of the full distance matrix."""
+    q, t = _desc(query), _desc(train)
+    n, m = q.shape[0], t.shape[0]
+    idx = np.full((n, k), NO_IDX, np.int32)
+    dist = np.full((n, k), NO_DIST, np.int32)
+    if n == 0 or m == 0:
+        return idx, dist
+    d = hamming_matrix_np(q, t)
+    order = np.argsort(d, axis=1, kind="stable")[:, :k]
+    kk = order.shape[1]
+    idx[:, :kk] = order
+    dist[:, :kk] = np.take_along_axis(d, order, 1)
+    return idx, dist
+
+
+def bf_match_np(source: np.ndarray, query: np.ndarray, dist_threshold: Optional[float] = None):
+    idx, dist = bf_knn_np(query, source, 1)
+    has = idx[:, 0] >= 0
+    q = np.nonzero(has)[0].astype(np.int32)
+    t = idx[has, 0]
+    d = dist[has, 0].astype(np.float32)
+    if dist_threshold and len(q) != 0:
+        lim = max(2 * float(d.min()), dist_threshold)
+        keep = d < lim
+        q, t, d = q[keep], t[keep], d[keep]
+    return q, t, d
+
+
+def bf_cross_check_np(query: np.ndarray, train: np.ndarray):
+    q, t = _desc(query), _desc(train)
+    n, m = q.shape[0], t.shape[0]
+    oi = np.full(n, NO_IDX, np.int32)
+    od = np.full(n, NO_DIST, np.int32)
+    if n == 0 or m == 0:
+        return oi, od
+    d = hamming_matrix_np(t, q)              # [M, N]
+    tq = np.argmin(d, axis=1)                 # first minimum = lowest query index
+    td = d[np.arange(m), tq]
+    for ti in range(m):                       # ascending train rows, strict <
+        if td[ti] < od[tq[ti]]:
+            od[tq[ti]] = td[ti]
+            oi[tq[ti]] = ti
+    return oi, od
+
+
+# --------------------------------------------------------------------------
+# reprojection residual / Jacobian
+# --------------------------------------------------------------------------
+def poses_to_rt12(T: np.ndarray) -> np.ndarray:
+    """[K,4,4] (or [K,3,4]) Tcw matrices -> [K,12] rows of [R|t]."""
+    T = np.asarray(T, np.float64)
+    return np.ascontiguousarray(T[:, :3, :4].reshape(T.shape[0], 12))
+
+
+def reproj_rj_c(poses12, points, obs_pose, obs_point, meas, fx, fy, cx, cy, with_point=True, threads=1):
+    poses12 = np.ascontiguousarray(poses12, np.float64)
+    points = np.ascontiguousarray(points, np.float64)
+    obs_pose = np.ascontiguousarray(obs_pose, np.int32)
+    obs_point = np.ascontiguousarray(obs_point, np.int32)
+    meas = np.ascontiguousarray(meas, np.float64)
+    O = obs_pose.shape[0]
+    e = np.empty((O, 2))
+    Jp = np.empty((O, 2, 6))
+    Jq = np.empty((O, 2, 3)) if with_point else None
+    rc = _load().oracle_reproj_rj_f64(_p(poses12), poses12.shape[0], _p(points), points.shape[0], _p(obs_pose),
+                                      _p(obs_point), _p(meas), O, fx, fy, cx, cy, _p(e), _p(Jp), _p(Jq), threads)
+    assert rc == 0
+    return e, Jp, Jq
+
+
+def reproj_rj_np(poses12, points, obs_pose, obs_point, meas, fx, fy, cx, cy):
+    """frontend.py:272-291 per observation, with numpy objects shaped as the callbacks see them."""
+    K = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1]], dtype=np.float64)  # primitives.py:25-29
+    O = len(obs_pose)
+    e = np.empty((O, 2))
+    Jp = np.empty((O, 2, 6))
+    Jq = np.empty((O, 2, 3))
+    for o in range(O):
+        P = np.asarray(poses12[obs_pose[o]], np.float64).reshape(3, 4)
+        R, t = P[:, :3], P[:, 3]
+        pos3d = np.asarray(points[obs_point[o]], np.float64)
+        pos_cam = R @ pos3d + t                      # T * self.pos3d
+        pos_pixel = K @ pos_cam
+        pos_pixel = pos_pixel / pos_pixel[2]
+        e[o] = np.asarray(meas[o], np.float64) - pos_pixel[:2]
+        X, Y, Z = pos_cam
+        Zinv = 1.0 / (Z + 1e-18)
+        Zinv2 = Zinv ** 2
+        Jp[o] = np.array([
+            [fx * X * Y * Zinv2, -fx - fx * X * X * Zinv2, fx * Y * Zinv, -fx * Zinv, 0, fx * X * Zinv2],
+            [fy + fy * Y * Y * Zinv2, -fy * X * Y * Zinv2, -fy * X * Zinv, 0, -fy * Zinv, fy * Y * Zinv2],
+        ])
+        A = np.array([[fx * Zinv, 0, -fx * X * Zinv2], [0, fy * Zinv, -fy * Y * Zinv2]])
+        Jq[o] = -A @ R
+    return e, Jp, Jq
+
+
+def pose_normal_eq_c(pose12, points, meas, active, fx, fy, cx, cy, huber_delta):
+    pose12 = np.ascontiguousarray(pose12, np.float64).reshape(12)
+    points = np.ascontiguousarray(points, np.float64)
+    meas = np.ascontiguousarray(meas, np.float64)
+    act = None if active is None else np.ascontiguousarray(active, np.uint8)
+    O = points.shape[0]
+    H = np.empty((6, 6))
+    b = np.empty(6)
+    chi2 = np.empty(O)
+    rc = _load().oracle_pose_normal_eq_f64(_p(pose12), _p(points), _p(meas), _p(act), O, fx, fy, cx, cy,
+                                           float(huber_delta), _p(H), _p(b), _p(chi2))
+    assert rc == 0
+    return H, b, chi2

@@ -1,0 +1,68 @@
+"""Drop-in for the reference's ``backend.py`` with a GPU-backed ``Backend``.
+
+The reference's ``Backend`` is an empty stub (``backend.py:101-103``) and its
+``Map`` container is unrelated to the hot path, so this module
+
+* re-exports the reference's own ``Map`` when a reference ``backend.py`` is
+  further down ``sys.path`` (overlay install; nothing is copied), and
+* defines ``Backend`` — still zero-argument constructible — with the
+  per-observation residual/Jacobian build (``frontend.py:272-291`` arithmetic)
+  running on MI355X through ``libslamhip.so``.
+
+No CPU fallback: without the library or a gfx950 GPU the methods raise.
+"""
+from __future__ import annotations
+
+import importlib.util
+import os
+import sys
+from typing import Optional
+
+import numpy as np
+
+from slamhip import reproj as _r
+from slamhip.device import Context, default_context
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _load_reference_backend():
+    """Find a `backend.py` on sys.path other than this one (the reference's) and load it."""
+    for entry in sys.path:
+        base = os.path.abspath(entry or os.getcwd())
+        if base == _HERE:
+            continue
+        cand = os.path.join(base, "backend.py")
+        if os.path.isfile(cand):
+            spec = importlib.util.spec_from_file_location("_reference_backend", cand)
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            return mod
+    return None
+
+
+def __getattr__(name: str):
+    if name == "Map":  # resolved lazily so the module imports without the reference present
+        ref = _load_reference_backend()
+        if ref is None or not hasattr(ref, "Map"):
+            raise ImportError("Map lives in the reference's backend.py, which is not on sys.path")
+        globals()["Map"] = ref.Map
+        return ref.Map
+    raise AttributeError(f"module 'backend' has no attribute {name!r}")
+
+
+class Backend:
+    def __init__(self):
+        self._ctx: Optional[Context] = None
+
+    @property
+    def ctx(self) -> Context:
+        if self._ctx is None:
+            self._ctx = default_context()
+        return self._ctx
+
+    def build_linearization(self, poses, points, obs_pose_idx, obs_point_idx, meas, fx, fy, cx, cy,
+                            with_point: bool = True):
+        """Residuals and Jacobians of every observation: (e [O,2], J_pose [O,2,6], J_point [O,2,3])."""
+        return _r.build_linearization(poses, points, obs_pose_idx, obs_point_idx, meas, fx, fy, cx, cy,
+                                      with_point, self.ctx)

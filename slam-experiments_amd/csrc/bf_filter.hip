@@ -1,0 +1,154 @@
+// bf_filter.hip — post-match selection on the device: the reference's
+// "distance < max(2*min_dist, dist_threshold)" filter
+// (feature_matchers.py:41-43), plus Lowe ratio and OpenCV crossCheck, which
+// BASELINE.json names as extensions (the reference itself never uses them).
+#include "internal.h"
+
+struct filter_scratch {        // lives at the start of the ctx workspace tail
+    int min_dist;              // min 1-NN distance over all queries
+    int pad;
+    unsigned long long count;  // rows kept
+};
+
+__device__ __forceinline__ int wave_min_i32(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+__global__ __launch_bounds__(256) void filter_init_kernel(filter_scratch* s) {
+    s->min_dist = SLAM_NO_MATCH_DIST;
+    s->pad = 0;
+    s->count = 0ull;
+}
+
+// min over queries of the 1-NN distance: wavefront min reduction, one atomic per wave
+__global__ __launch_bounds__(256) void filter_min_kernel(const int2* __restrict__ idx, const int2* __restrict__ dist,
+                                                         int N, filter_scratch* s) {
+    int m = SLAM_NO_MATCH_DIST;
+    for (int n = blockIdx.x * 256 + threadIdx.x; n < N; n += gridDim.x * 256)
+        if (idx[n].x >= 0) m = min(m, dist[n].x);
+    m = wave_min_i32(m);
+    if ((threadIdx.x & 63) == 0 && m != SLAM_NO_MATCH_DIST) atomicMin(&s->min_dist, m);
+}
+
+__global__ __launch_bounds__(256) void filter_keep_kernel(const int2* __restrict__ idx, const int2* __restrict__ dist,
+                                                          int N, int mode, double param, filter_scratch* s,
+                                                          uint8_t* __restrict__ keep) {
+    const int min_dist = s->min_dist;
+    unsigned int kept = 0;
+    for (int n = blockIdx.x * 256 + threadIdx.x; n < N; n += gridDim.x * 256) {
+        const int2 i = idx[n], d = dist[n];
+        bool k = i.x >= 0;
+        if (mode == 1) {
+            // feature_matchers.py:43: m.distance < max(2 * min_dist, dist_threshold); distance is the
+            // float32 image of an integer <= 256, so the comparison is exact in f64
+            const double lim = fmax(2.0 * (double)min_dist, param);
+            k = k && (double)d.x < lim;
+        } else if (mode == 2) {
+            // Lowe: m.distance < ratio * n.distance in float32-valued doubles (what the Python idiom computes)
+            k = k && i.y >= 0 && (double)d.x < param * (double)d.y;
+        }
+        keep[n] = k ? 1 : 0;
+        kept += k ? 1u : 0u;
+    }
+    // ballot-free wave sum, then one atomic per wave
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) kept += __shfl_xor(kept, off, 64);
+    if ((threadIdx.x & 63) == 0 && kept) atomicAdd(&s->count, (unsigned long long)kept);
+}
+
+static int filter_scratch_ptr(slam_ctx* ctx, filter_scratch** out) {
+    *out = (filter_scratch*)ctx->scratch;  // 4 KiB per-context device scratch, allocated at ctx creation
+    return SLAM_OK;
+}
+
+extern "C" int slam_bf_match_filter(slam_ctx* ctx, const int32_t* d_idx, const int32_t* d_dist, int64_t N,
+                                    int mode, double param, uint8_t* d_keep, int64_t* h_count,
+                                    int32_t* h_min_dist) {
+    SLAM_REQUIRE(ctx, "slam_bf_match_filter: null ctx");
+    SLAM_REQUIRE(mode >= 0 && mode <= 2, "mode %d not in {0,1,2}", mode);
+    SLAM_REQUIRE(N >= 0 && N <= (1ll << 30), "bad N=%lld", (long long)N);
+    if (h_count) *h_count = 0;
+    if (h_min_dist) *h_min_dist = SLAM_NO_MATCH_DIST;
+    if (N == 0) return SLAM_OK;
+    SLAM_REQUIRE(d_idx && d_dist && d_keep, "slam_bf_match_filter: null device pointer");
+    SLAM_HIP(hipSetDevice(ctx->device));
+    filter_scratch* s = nullptr;
+    if (int rc = filter_scratch_ptr(ctx, &s)) return rc;
+    const int blocks = (int)((N + 255) / 256 < 2048 ? (N + 255) / 256 : 2048);
+    filter_init_kernel<<<1, 1, 0, ctx->stream>>>(s);
+    filter_min_kernel<<<blocks, 256, 0, ctx->stream>>>((const int2*)d_idx, (const int2*)d_dist, (int)N, s);
+    filter_keep_kernel<<<blocks, 256, 0, ctx->stream>>>((const int2*)d_idx, (const int2*)d_dist, (int)N, mode,
+                                                        param, s, d_keep);
+    SLAM_HIP(hipGetLastError());
+    filter_scratch h;
+    SLAM_HIP(hipMemcpyAsync(&h, s, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    SLAM_HIP(hipStreamSynchronize(ctx->stream));
+    if (h_count) *h_count = (int64_t)h.count;
+    if (h_min_dist) *h_min_dist = h.min_dist;
+    return SLAM_OK;
+}
+
+// ---- crossCheck ------------------------------------------------------------
+// slot[q] = min over train rows t whose nearest query is q of (dist << 32 | t)
+__global__ __launch_bounds__(256) void cross_init_kernel(unsigned long long* slot, int N) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n < N) slot[n] = ~0ull;
+}
+
+__global__ __launch_bounds__(256) void cross_scatter_kernel(const int2* __restrict__ rev_idx,
+                                                            const int2* __restrict__ rev_dist, int M, int N,
+                                                            unsigned long long* slot) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= M) return;
+    const int q = rev_idx[t].x;
+    if (q < 0 || q >= N) return;
+    const unsigned long long key = ((unsigned long long)(unsigned)rev_dist[t].x << 32) | (unsigned)t;
+    atomicMin(&slot[q], key);
+}
+
+__global__ __launch_bounds__(256) void cross_emit_kernel(const unsigned long long* __restrict__ slot, int N,
+                                                         int* __restrict__ out_idx, int* __restrict__ out_dist,
+                                                         filter_scratch* s) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    unsigned int kept = 0;
+    if (n < N) {
+        const unsigned long long k = slot[n];
+        const bool has = k != ~0ull;
+        out_idx[n] = has ? (int)(unsigned)k : SLAM_NO_MATCH_IDX;
+        out_dist[n] = has ? (int)(k >> 32) : SLAM_NO_MATCH_DIST;
+        kept = has ? 1u : 0u;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) kept += __shfl_xor(kept, off, 64);
+    if ((threadIdx.x & 63) == 0 && kept) atomicAdd(&s->count, (unsigned long long)kept);
+}
+
+extern "C" int slam_bf_cross_check(slam_ctx* ctx, const int32_t* d_rev_idx, const int32_t* d_rev_dist, int64_t M,
+                                   int64_t N, int32_t* d_out_idx, int32_t* d_out_dist, int64_t* h_count) {
+    SLAM_REQUIRE(ctx, "slam_bf_cross_check: null ctx");
+    SLAM_REQUIRE(N >= 0 && M >= 0 && N <= (1ll << 30) && M <= (1ll << 30), "bad sizes");
+    if (h_count) *h_count = 0;
+    if (N == 0) return SLAM_OK;
+    SLAM_REQUIRE(d_out_idx && d_out_dist && (M == 0 || (d_rev_idx && d_rev_dist)),
+                 "slam_bf_cross_check: null device pointer");
+    SLAM_HIP(hipSetDevice(ctx->device));
+    filter_scratch* s = nullptr;
+    if (int rc = filter_scratch_ptr(ctx, &s)) return rc;
+    void* ws = nullptr;
+    if (int rc = slam_workspace(ctx, (uint64_t)N * 8, &ws)) return rc;
+    unsigned long long* slot = (unsigned long long*)ws;
+    filter_init_kernel<<<1, 1, 0, ctx->stream>>>(s);
+    cross_init_kernel<<<(unsigned)((N + 255) / 256), 256, 0, ctx->stream>>>(slot, (int)N);
+    if (M)
+        cross_scatter_kernel<<<(unsigned)((M + 255) / 256), 256, 0, ctx->stream>>>(
+            (const int2*)d_rev_idx, (const int2*)d_rev_dist, (int)M, (int)N, slot);
+    cross_emit_kernel<<<(unsigned)((N + 255) / 256), 256, 0, ctx->stream>>>(slot, (int)N, d_out_idx, d_out_dist, s);
+    SLAM_HIP(hipGetLastError());
+    filter_scratch h;
+    SLAM_HIP(hipMemcpyAsync(&h, s, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    SLAM_HIP(hipStreamSynchronize(ctx->stream));
+    if (h_count) *h_count = (int64_t)h.count;
+    return SLAM_OK;
+}

@@ -1,0 +1,381 @@
+// bf_hamming.hip — brute-force Hamming top-2 over 256-bit ORB descriptors on
+// gfx950 (MI355X).  Replaces cv2.BFMatcher(NORM_HAMMING).match / knnMatch(k=2)
+// behind BruteForceFeatureMatcher.match (reference feature_matchers.py:33-39).
+//
+// Design:
+//   * lane <-> query: every lane keeps R query descriptors in registers
+//     (8*R VGPRs), so the per-query top-2 lives in registers and never needs a
+//     cross-lane reduction.
+//   * train rows are staged global -> LDS with coalesced 16-B loads (one
+//     256-row / 8-KiB tile per step, double buffered) and read back as
+//     wave-uniform (broadcast) ds_read_b128, so one LDS read feeds 64*R pairs.
+//   * inner op per 32-bit word: v_xor_b32 + accumulating v_bcnt_u32_b32 =
+//     16 VALU ops per 256-bit pair, the floor for this ISA without MFMA.
+//   * top-2 maintenance is filtered: each accumulator starts at
+//     2^31 - (current 2nd-best distance), so "some query of this lane improved"
+//     is one unsigned min-tree + one compare per R pairs; the wave skips the
+//     update block with a ballot-style exec branch (s_and_saveexec /
+//     s_cbranch_execz) when no lane improved.  The update itself is
+//     branch-free on packed keys (dist << 23 | train index): 2nd = med3,
+//     1st = min, which keeps OpenCV's (distance asc, index asc) order because
+//     keys are unique and compare lexicographically.
+//   * the train axis is split into chunks (grid.y) so small and large N both
+//     fill 256 CUs; partial top-2 keys go to a workspace and a second tiny
+//     kernel merges and decodes them to (int32 idx, int32 dist).
+#include "internal.h"
+#include <stdio.h>
+
+typedef uint32_t u32;
+
+#define SLAM_TILE_ROWS 256          // train rows per LDS tile (8 KiB)
+#define SLAM_KEY_IDX_BITS 23
+#define SLAM_KEY_IDX_MASK 0x7FFFFFu
+#define SLAM_KEY_NONE 0xFFFFFFFFu
+#define SLAM_ACC_BIAS 0x80000000u
+
+// D = popcount(x) + acc in ONE instruction.  Written as asm because hipcc
+// re-associates __builtin_popcount(x)+acc chains into bcnt(x,0)+v_add3 (20
+// instead of 16 VALU ops per pair).
+__device__ __forceinline__ u32 bcnt_acc(u32 x, u32 acc) {
+    u32 d;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(acc));
+    return d;
+}
+__device__ __forceinline__ u32 umin3(u32 a, u32 b, u32 c) { return min(min(a, b), c); }
+__device__ __forceinline__ u32 umed3(u32 a, u32 b, u32 c) { return max(min(a, b), min(max(a, b), c)); }
+
+template <int R>
+__device__ __forceinline__ u32 min_all(const u32 (&acc)[R]) {
+    if constexpr (R == 1) return acc[0];
+    else if constexpr (R == 2) return min(acc[0], acc[1]);
+    else if constexpr (R == 4) return min(umin3(acc[0], acc[1], acc[2]), acc[3]);
+    else {
+        static_assert(R == 8, "R must be 1, 2, 4 or 8");
+        u32 m0 = umin3(acc[0], acc[1], acc[2]);
+        u32 m1 = umin3(acc[3], acc[4], acc[5]);
+        return min(umin3(m0, m1, acc[6]), acc[7]);
+    }
+}
+
+// one train row (a = words 0-3, b = words 4-7) against the lane's R queries
+template <int R>
+__device__ __forceinline__ void step(const u32 (&q)[R][8], const uint4 a, const uint4 b, u32 train_idx,
+                                     u32 (&b1)[R], u32 (&b2)[R], u32 (&init)[R]) {
+    u32 acc[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) acc[r] = bcnt_acc(q[r][0] ^ a.x, init[r]);
+#pragma unroll
+    for (int r = 0; r < R; r++) acc[r] = bcnt_acc(q[r][1] ^ a.y, acc[r]);
+#pragma unroll
+    for (int r = 0; r < R; r++) acc[r] = bcnt_acc(q[r][2] ^ a.z, acc[r]);
+#pragma unroll
+    for (int r = 0; r < R; r++) acc[r] = bcnt_acc(q[r][3] ^ a.w, acc[r]);
+#pragma unroll
+    for (int r = 0; r < R; r++) acc[r] = bcnt_acc(q[r][4] ^ b.x, acc[r]);
+#pragma unroll
+    for (int r = 0; r < R; r++) acc[r] = bcnt_acc(q[r][5] ^ b.y, acc[r]);
+#pragma unroll
+    for (int r = 0; r < R; r++) acc[r] = bcnt_acc(q[r][6] ^ b.z, acc[r]);
+#pragma unroll
+    for (int r = 0; r < R; r++) acc[r] = bcnt_acc(q[r][7] ^ b.w, acc[r]);
+    // acc[r] = 2^31 - d2[r] + d  =>  d < d2[r]  <=>  acc[r] < 2^31
+    if (min_all<R>(acc) < SLAM_ACC_BIAS) {
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            u32 key = ((acc[r] - init[r]) << SLAM_KEY_IDX_BITS) | train_idx;
+            b2[r] = umed3(b1[r], b2[r], key);   // second smallest of {b1, b2, key}
+            b1[r] = min(b1[r], key);
+            init[r] = SLAM_ACC_BIAS - (b2[r] >> SLAM_KEY_IDX_BITS);
+        }
+    }
+}
+
+// grid.x = query blocks of 256*R rows, grid.y = train chunks of `chunk` rows.
+// partial[chunk][query] = (best key, second key), key = dist << 23 | train row
+// (row relative to d_train of this launch), 0xFFFFFFFF = none.
+template <int R>
+__global__ __launch_bounds__(256) void bf_top2_kernel(const uint4* __restrict__ q, int N,
+                                                      const uint4* __restrict__ t, int M, int chunk,
+                                                      uint2* __restrict__ partial) {
+    __shared__ uint4 tile[2][SLAM_TILE_ROWS * 2];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int qbase = blockIdx.x * (256 * R) + wave * (64 * R) + lane;
+
+    u32 qr[R][8];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        int qi = qbase + r * 64;
+        qi = qi < N ? qi : N - 1;  // clamp: tail lanes compute a duplicate and never store
+        const uint4 a = q[2 * (size_t)qi], b = q[2 * (size_t)qi + 1];
+        qr[r][0] = a.x; qr[r][1] = a.y; qr[r][2] = a.z; qr[r][3] = a.w;
+        qr[r][4] = b.x; qr[r][5] = b.y; qr[r][6] = b.z; qr[r][7] = b.w;
+    }
+    u32 b1[R], b2[R], init[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        b1[r] = SLAM_KEY_NONE;
+        b2[r] = SLAM_KEY_NONE;
+        init[r] = SLAM_ACC_BIAS - (SLAM_KEY_NONE >> SLAM_KEY_IDX_BITS);  // "distance 511": everything enters
+    }
+
+    const int t0 = blockIdx.y * chunk;
+    const int t1 = min(M, t0 + chunk);
+
+    // prologue: first tile -> LDS buffer 0
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int g = 2 * t0 + tid + i * 256;
+        tile[0][tid + i * 256] = g < 2 * t1 ? t[(size_t)g] : make_uint4(0, 0, 0, 0);
+    }
+    __syncthreads();
+
+    int buf = 0;
+    for (int tb = t0; tb < t1; tb += SLAM_TILE_ROWS) {
+        // issue the next tile's global loads before computing on this one
+        const int nb = tb + SLAM_TILE_ROWS;
+        uint4 nxt[2];
+        if (nb < t1) {
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                const int g = 2 * nb + tid + i * 256;
+                nxt[i] = g < 2 * t1 ? t[(size_t)g] : make_uint4(0, 0, 0, 0);
+            }
+        }
+        const int cnt = __builtin_amdgcn_readfirstlane(min(SLAM_TILE_ROWS, t1 - tb));
+        const uint4* tp = tile[buf];
+        int j = 0;
+        for (; j + 2 <= cnt; j += 2) {
+            const uint4 a0 = tp[2 * j], c0 = tp[2 * j + 1];
+            const uint4 a1 = tp[2 * j + 2], c1 = tp[2 * j + 3];
+            step<R>(qr, a0, c0, (u32)(tb + j), b1, b2, init);
+            step<R>(qr, a1, c1, (u32)(tb + j + 1), b1, b2, init);
+        }
+        if (j < cnt) {
+            const uint4 a0 = tp[2 * j], c0 = tp[2 * j + 1];
+            step<R>(qr, a0, c0, (u32)(tb + j), b1, b2, init);
+        }
+        if (nb < t1) {
+#pragma unroll
+            for (int i = 0; i < 2; i++) tile[buf ^ 1][tid + i * 256] = nxt[i];
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int qi = qbase + r * 64;
+        if (qi < N) partial[(size_t)blockIdx.y * N + qi] = make_uint2(b1[r], b2[r]);
+    }
+}
+
+// merge S partial key tables and decode to (idx + train_base, dist)
+__global__ __launch_bounds__(256) void bf_merge_keys_kernel(const uint2* __restrict__ partial, int S, int N,
+                                                            int train_base, int2* __restrict__ idx,
+                                                            int2* __restrict__ dist) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    u32 b1 = SLAM_KEY_NONE, b2 = SLAM_KEY_NONE;
+    for (int s = 0; s < S; s++) {
+        const uint2 p = partial[(size_t)s * N + n];
+        b2 = umed3(b1, b2, p.x);
+        b1 = min(b1, p.x);
+        b2 = umed3(b1, b2, p.y);
+        b1 = min(b1, p.y);
+    }
+    int2 oi, od;
+    oi.x = b1 == SLAM_KEY_NONE ? SLAM_NO_MATCH_IDX : (int)(b1 & SLAM_KEY_IDX_MASK) + train_base;
+    od.x = b1 == SLAM_KEY_NONE ? SLAM_NO_MATCH_DIST : (int)(b1 >> SLAM_KEY_IDX_BITS);
+    oi.y = b2 == SLAM_KEY_NONE ? SLAM_NO_MATCH_IDX : (int)(b2 & SLAM_KEY_IDX_MASK) + train_base;
+    od.y = b2 == SLAM_KEY_NONE ? SLAM_NO_MATCH_DIST : (int)(b2 >> SLAM_KEY_IDX_BITS);
+    idx[n] = oi;
+    dist[n] = od;
+}
+
+// merge G decoded tables by (dist, idx)
+__global__ __launch_bounds__(256) void bf_merge_tables_kernel(const int2* __restrict__ idx_parts,
+                                                              const int2* __restrict__ dist_parts, int G, int N,
+                                                              int2* __restrict__ idx, int2* __restrict__ dist) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const uint64_t NONE = ~0ull;
+    uint64_t k1 = NONE, k2 = NONE;
+    for (int g = 0; g < G; g++) {
+        const int2 pi = idx_parts[(size_t)g * N + n], pd = dist_parts[(size_t)g * N + n];
+        const uint64_t ka = pi.x < 0 ? NONE : ((uint64_t)(u32)pd.x << 32) | (u32)pi.x;
+        const uint64_t kb = pi.y < 0 ? NONE : ((uint64_t)(u32)pd.y << 32) | (u32)pi.y;
+        // insert ka then kb, keeping the two smallest
+        uint64_t lo = k1 < ka ? k1 : ka, hi = k1 < ka ? ka : k1;
+        k1 = lo; k2 = k2 < hi ? k2 : hi;
+        lo = k1 < kb ? k1 : kb; hi = k1 < kb ? kb : k1;
+        k1 = lo; k2 = k2 < hi ? k2 : hi;
+    }
+    int2 oi, od;
+    oi.x = k1 == NONE ? SLAM_NO_MATCH_IDX : (int)(u32)k1;
+    od.x = k1 == NONE ? SLAM_NO_MATCH_DIST : (int)(k1 >> 32);
+    oi.y = k2 == NONE ? SLAM_NO_MATCH_IDX : (int)(u32)k2;
+    od.y = k2 == NONE ? SLAM_NO_MATCH_DIST : (int)(k2 >> 32);
+    idx[n] = oi;
+    dist[n] = od;
+}
+
+__global__ __launch_bounds__(256) void bf_fill_none_kernel(int N, int2* __restrict__ idx, int2* __restrict__ dist) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    idx[n] = make_int2(SLAM_NO_MATCH_IDX, SLAM_NO_MATCH_IDX);
+    dist[n] = make_int2(SLAM_NO_MATCH_DIST, SLAM_NO_MATCH_DIST);
+}
+
+// ---- host side -----------------------------------------------------------
+
+struct bf_plan {
+    int R;        // queries per lane
+    int qblocks;  // grid.x
+    int chunk;    // train rows per chunk (multiple of the LDS tile)
+    int S;        // grid.y
+};
+
+// tuning overrides (0 = heuristic); set through slam_bf_set_tuning
+static int g_force_R = 0;
+static int g_blocks_per_cu = 0;
+
+extern "C" int slam_bf_set_tuning(int R, int blocks_per_cu) {
+    SLAM_REQUIRE(R == 0 || R == 1 || R == 2 || R == 4 || R == 8, "R must be 0, 1, 2, 4 or 8");
+    SLAM_REQUIRE(blocks_per_cu >= 0 && blocks_per_cu <= 64, "blocks_per_cu out of range");
+    g_force_R = R;
+    g_blocks_per_cu = blocks_per_cu;
+    return SLAM_OK;
+}
+
+static bf_plan make_plan(const slam_ctx* ctx, int64_t N, int64_t M) {
+    bf_plan p;
+    const int64_t target = (int64_t)ctx->num_cu * (g_blocks_per_cu ? g_blocks_per_cu : 4);
+    const int64_t max_chunks = (M + SLAM_TILE_ROWS - 1) / SLAM_TILE_ROWS;
+    // largest R whose grid can still reach the target block count
+    int R = 8;
+    if (g_force_R) R = g_force_R;
+    else
+        while (R > 1 && ((N + 256 * R - 1) / (256 * R)) * max_chunks < target) R >>= 1;
+    p.R = R;
+    p.qblocks = (int)((N + 256 * R - 1) / (256 * R));
+    int64_t S = (target + p.qblocks - 1) / p.qblocks;
+    if (S > max_chunks) S = max_chunks;
+    if (S < 1) S = 1;
+    int64_t chunk = (M + S - 1) / S;
+    chunk = (chunk + SLAM_TILE_ROWS - 1) / SLAM_TILE_ROWS * SLAM_TILE_ROWS;
+    p.chunk = (int)chunk;
+    p.S = (int)((M + chunk - 1) / chunk);
+    return p;
+}
+
+// one pass over at most 2^23 train rows
+static int bf_pass(slam_ctx* ctx, const void* d_query, int64_t N, const void* d_train, int64_t M,
+                   int64_t train_base, void* ws, int32_t* d_idx, int32_t* d_dist) {
+    const bf_plan p = make_plan(ctx, N, M);
+    uint2* partial = (uint2*)ws;
+    const dim3 grid(p.qblocks, p.S), block(256);
+    const uint4* q = (const uint4*)d_query;
+    const uint4* t = (const uint4*)d_train;
+    SLAM_HIP(hipGetLastError());
+    if (int rc = slam_prof_begin(ctx)) return rc;
+    switch (p.R) {
+        case 8: bf_top2_kernel<8><<<grid, block, 0, ctx->stream>>>(q, (int)N, t, (int)M, p.chunk, partial); break;
+        case 4: bf_top2_kernel<4><<<grid, block, 0, ctx->stream>>>(q, (int)N, t, (int)M, p.chunk, partial); break;
+        case 2: bf_top2_kernel<2><<<grid, block, 0, ctx->stream>>>(q, (int)N, t, (int)M, p.chunk, partial); break;
+        default: bf_top2_kernel<1><<<grid, block, 0, ctx->stream>>>(q, (int)N, t, (int)M, p.chunk, partial); break;
+    }
+    if (int rc = slam_prof_end(ctx)) return rc;
+    SLAM_HIP(hipGetLastError());
+    bf_merge_keys_kernel<<<dim3((unsigned)((N + 255) / 256)), block, 0, ctx->stream>>>(
+        partial, p.S, (int)N, (int)train_base, (int2*)d_idx, (int2*)d_dist);
+    SLAM_HIP(hipGetLastError());
+    return SLAM_OK;
+}
+
+static uint64_t partial_bytes(const slam_ctx* ctx, int64_t N, int64_t M) {
+    const bf_plan p = make_plan(ctx, N, M);
+    return (uint64_t)p.S * (uint64_t)N * sizeof(uint2);
+}
+
+extern "C" int slam_bf_knn2_u256(slam_ctx* ctx, const void* d_query, int64_t N, const void* d_train,
+                                 int64_t M, int64_t train_base, int32_t* d_idx, int32_t* d_dist) {
+    SLAM_REQUIRE(ctx, "slam_bf_knn2_u256: null ctx");
+    SLAM_REQUIRE(N >= 0 && M >= 0, "negative size (N=%lld, M=%lld)", (long long)N, (long long)M);
+    SLAM_REQUIRE(N <= (1ll << 30), "N=%lld exceeds 2^30 query rows per call", (long long)N);
+    SLAM_REQUIRE(train_base >= 0 && train_base + M <= 0x7FFFFFFFll, "train_base + M must fit int32");
+    if (N == 0) return SLAM_OK;
+    SLAM_REQUIRE(d_query && d_idx && d_dist, "slam_bf_knn2_u256: null device pointer");
+    SLAM_REQUIRE(((uintptr_t)d_query & 15) == 0 && ((uintptr_t)d_train & 15) == 0,
+                 "descriptor pointers must be 16-byte aligned");
+    SLAM_HIP(hipSetDevice(ctx->device));
+    if (M == 0) {
+        bf_fill_none_kernel<<<dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream>>>(
+            (int)N, (int2*)d_idx, (int2*)d_dist);
+        SLAM_HIP(hipGetLastError());
+        return SLAM_OK;
+    }
+    SLAM_REQUIRE(d_train, "slam_bf_knn2_u256: null train pointer");
+    const int64_t PASS = SLAM_MAX_TRAIN_PER_PASS;
+    const int64_t passes = (M + PASS - 1) / PASS;
+    if (passes == 1) {
+        void* ws = nullptr;
+        if (int rc = slam_workspace(ctx, partial_bytes(ctx, N, M), &ws)) return rc;
+        return bf_pass(ctx, d_query, N, d_train, M, train_base, ws, d_idx, d_dist);
+    }
+    // train set larger than one key range: run passes into per-pass tables, then merge them
+    const uint64_t pb = partial_bytes(ctx, N, PASS);
+    const uint64_t tb = (uint64_t)passes * N * 2 * sizeof(int32_t);
+    void* ws = nullptr;
+    if (int rc = slam_workspace(ctx, pb + 2 * tb + 64, &ws)) return rc;
+    char* base = (char*)ws;
+    int32_t* idx_parts = (int32_t*)(base + ((pb + 15) & ~15ull));
+    int32_t* dist_parts = (int32_t*)((char*)idx_parts + tb);
+    for (int64_t p = 0; p < passes; p++) {
+        const int64_t m0 = p * PASS, m = (M - m0) < PASS ? (M - m0) : PASS;
+        if (int rc = bf_pass(ctx, d_query, N, (const char*)d_train + m0 * SLAM_DESC_BYTES, m, train_base + m0, ws,
+                             idx_parts + p * N * 2, dist_parts + p * N * 2))
+            return rc;
+    }
+    return slam_bf_merge_top2(ctx, idx_parts, dist_parts, passes, N, d_idx, d_dist);
+}
+
+extern "C" int slam_bf_merge_top2(slam_ctx* ctx, const int32_t* d_idx_parts, const int32_t* d_dist_parts,
+                                  int64_t G, int64_t N, int32_t* d_idx, int32_t* d_dist) {
+    SLAM_REQUIRE(ctx, "slam_bf_merge_top2: null ctx");
+    SLAM_REQUIRE(G >= 1 && N >= 0 && N <= (1ll << 30), "bad sizes (G=%lld, N=%lld)", (long long)G, (long long)N);
+    if (N == 0) return SLAM_OK;
+    SLAM_REQUIRE(d_idx_parts && d_dist_parts && d_idx && d_dist, "slam_bf_merge_top2: null device pointer");
+    SLAM_HIP(hipSetDevice(ctx->device));
+    bf_merge_tables_kernel<<<dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream>>>(
+        (const int2*)d_idx_parts, (const int2*)d_dist_parts, (int)G, (int)N, (int2*)d_idx, (int2*)d_dist);
+    SLAM_HIP(hipGetLastError());
+    return SLAM_OK;
+}
+
+extern "C" int slam_bf_knn2_u256_host(slam_ctx* ctx, const uint8_t* h_query, int64_t N, const uint8_t* h_train,
+                                      int64_t M, int32_t* h_idx, int32_t* h_dist) {
+    SLAM_REQUIRE(ctx, "slam_bf_knn2_u256_host: null ctx");
+    SLAM_REQUIRE(N >= 0 && M >= 0, "negative size");
+    if (N == 0) return SLAM_OK;
+    SLAM_REQUIRE(h_query && h_idx && h_dist && (h_train || M == 0), "slam_bf_knn2_u256_host: null host pointer");
+    void *dq = nullptr, *dt = nullptr, *di = nullptr, *dd = nullptr;
+    int rc = slam_malloc(ctx, (uint64_t)N * SLAM_DESC_BYTES, &dq);
+    if (!rc) rc = slam_malloc(ctx, (uint64_t)M * SLAM_DESC_BYTES, &dt);
+    if (!rc) rc = slam_malloc(ctx, (uint64_t)N * 8, &di);
+    if (!rc) rc = slam_malloc(ctx, (uint64_t)N * 8, &dd);
+    if (!rc) rc = slam_upload(ctx, dq, h_query, (uint64_t)N * SLAM_DESC_BYTES);
+    if (!rc && M) rc = slam_upload(ctx, dt, h_train, (uint64_t)M * SLAM_DESC_BYTES);
+    if (!rc) rc = slam_bf_knn2_u256(ctx, dq, N, dt, M, 0, (int32_t*)di, (int32_t*)dd);
+    if (!rc) rc = slam_download(ctx, h_idx, di, (uint64_t)N * 8);
+    if (!rc) rc = slam_download(ctx, h_dist, dd, (uint64_t)N * 8);
+    // keep the first error message: frees below must not overwrite it on failure
+    char saved[512];
+    if (rc) snprintf(saved, sizeof(saved), "%s", slam_last_error());
+    if (dq) slam_free(ctx, dq);
+    if (dt) slam_free(ctx, dt);
+    if (di) slam_free(ctx, di);
+    if (dd) slam_free(ctx, dd);
+    if (rc) slam_set_error(rc, "%s", saved);
+    return rc;
+}

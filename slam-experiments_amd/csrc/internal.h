@@ -1,0 +1,49 @@
+// internal.h — shared state of libslamhip.so (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdarg.h>
+#include <unordered_map>
+#include <mutex>
+#include "slamhip.h"
+
+struct slam_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    std::mutex mu;                                  // guards allocs / workspace growth
+    std::unordered_map<void*, uint64_t> allocs;     // device pointers handed out by slam_malloc
+    void* workspace = nullptr;                      // partial top-2 tables etc.
+    uint64_t workspace_bytes = 0;
+    int num_cu = 0;
+    void* scratch = nullptr;                        // 4 KiB device scratch (filter counters, reductions)
+    // profiling of the dominant kernel
+    int prof_on = 0;
+    static const int PROF_MAX = 4096;
+    hipEvent_t* prof_ev = nullptr;                  // 2*PROF_MAX events, created lazily
+    int prof_n = 0;
+    // RCCL
+    void* comm = nullptr;                           // ncclComm_t
+    int comm_rank = -1, comm_nranks = 0;
+};
+
+int slam_set_error(int code, const char* fmt, ...);
+
+#define SLAM_HIP(call)                                                              \
+    do {                                                                            \
+        hipError_t _e = (call);                                                     \
+        if (_e != hipSuccess)                                                       \
+            return slam_set_error(SLAM_ERR_HIP, "%s failed: %s (%s:%d)", #call,     \
+                                  hipGetErrorString(_e), __FILE__, __LINE__);       \
+    } while (0)
+
+#define SLAM_REQUIRE(cond, ...)                                                     \
+    do {                                                                            \
+        if (!(cond)) return slam_set_error(SLAM_ERR_INVALID, __VA_ARGS__);          \
+    } while (0)
+
+// grows ctx->workspace to at least `bytes` (stream-synchronising when it grows)
+int slam_workspace(slam_ctx* ctx, uint64_t bytes, void** out);
+// event bracket around the dominant kernel when profiling is on
+int slam_prof_begin(slam_ctx* ctx);
+int slam_prof_end(slam_ctx* ctx);

@@ -1,0 +1,112 @@
+"""Device context and buffers on top of the C ABI (one Context = one GPU + one stream)."""
+from __future__ import annotations
+
+import ctypes
+import threading
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import check
+
+
+class DeviceBuffer:
+    """A device allocation (or a view into one) owned by a Context."""
+
+    __slots__ = ("ctx", "ptr", "nbytes", "_owner")
+
+    def __init__(self, ctx: "Context", ptr: int, nbytes: int, owner: Optional["DeviceBuffer"] = None):
+        self.ctx = ctx
+        self.ptr = ptr
+        self.nbytes = nbytes
+        self._owner = owner
+
+    def view(self, offset: int, nbytes: Optional[int] = None) -> "DeviceBuffer":
+        nbytes = self.nbytes - offset if nbytes is None else nbytes
+        if offset < 0 or nbytes < 0 or offset + nbytes > self.nbytes:
+            raise ValueError("view out of range")
+        return DeviceBuffer(self.ctx, self.ptr + offset, nbytes, self._owner or self)
+
+    def upload(self, host: np.ndarray) -> "DeviceBuffer":
+        host = np.ascontiguousarray(host)
+        if host.nbytes > self.nbytes:
+            raise ValueError(f"upload of {host.nbytes} B into a {self.nbytes} B buffer")
+        check(self.ctx.lib.slam_upload(self.ctx.handle, self.ptr, host.ctypes.data, host.nbytes))
+        return self
+
+    def download(self, dtype, shape) -> np.ndarray:
+        out = np.empty(shape, dtype)
+        if out.nbytes > self.nbytes:
+            raise ValueError(f"download of {out.nbytes} B from a {self.nbytes} B buffer")
+        check(self.ctx.lib.slam_download(self.ctx.handle, out.ctypes.data, self.ptr, out.nbytes))
+        return out
+
+    def free(self) -> None:
+        if self._owner is None and self.ptr:
+            check(self.ctx.lib.slam_free(self.ctx.handle, self.ptr))
+            self.ptr = 0
+
+
+class Context:
+    """One HIP device + stream.  Raises if libslamhip or a gfx950 GPU is missing."""
+
+    def __init__(self, device: int = 0):
+        self.lib = _lib.load()
+        h = ctypes.c_void_p()
+        check(self.lib.slam_ctx_create(device, ctypes.byref(h)))
+        self.handle = h
+        self.device = device
+
+    def close(self) -> None:
+        if self.handle:
+            check(self.lib.slam_ctx_destroy(self.handle))
+            self.handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def malloc(self, nbytes: int) -> DeviceBuffer:
+        p = ctypes.c_void_p()
+        check(self.lib.slam_malloc(self.handle, int(nbytes), ctypes.byref(p)))
+        return DeviceBuffer(self, p.value or 0, int(nbytes))
+
+    def upload(self, host: np.ndarray) -> DeviceBuffer:
+        host = np.ascontiguousarray(host)
+        return self.malloc(host.nbytes).upload(host)
+
+    def sync(self) -> None:
+        check(self.lib.slam_sync(self.handle))
+
+    def timer_start(self) -> None:
+        check(self.lib.slam_timer_start(self.handle))
+
+    def timer_stop(self) -> float:
+        ms = ctypes.c_float(0)
+        check(self.lib.slam_timer_stop(self.handle, ctypes.byref(ms)))
+        return ms.value
+
+    def prof_enable(self, on: bool = True) -> None:
+        check(self.lib.slam_prof_enable(self.handle, int(on)))
+
+    def prof_read(self) -> Tuple[int, float]:
+        n = ctypes.c_int64(0)
+        ms = ctypes.c_double(0)
+        check(self.lib.slam_prof_read(self.handle, ctypes.byref(n), ctypes.byref(ms)))
+        return n.value, ms.value
+
+
+_default_lock = threading.Lock()
+_default_ctx: Optional[Context] = None
+
+
+def default_context() -> Context:
+    """Process-wide context on device 0 (what the drop-in matcher uses)."""
+    global _default_ctx
+    with _default_lock:
+        if _default_ctx is None:
+            _default_ctx = Context(0)
+        return _default_ctx

@@ -1,0 +1,211 @@
+"""Brute-force Hamming matching of 256-bit ORB descriptors on MI355X.
+
+Array-level API under the drop-in ``feature_matchers.BruteForceFeatureMatcher``.
+Semantics are those of ``cv2.BFMatcher(NORM_HAMMING)`` as the reference uses it
+(``feature_matchers.py:33-44``): per query row the nearest train rows ordered by
+(distance asc, train index asc).  Everything here runs on the GPU through
+``libslamhip.so``; there is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+from ._lib import DESC_BYTES, NO_MATCH_DIST, NO_MATCH_IDX, check
+from .device import Context, DeviceBuffer, default_context
+
+NORM_HAMMING = 6           # cv2.NORM_HAMMING, the only norm the reference constructs (slam.py:24)
+IMGIDX_SHIFT = 18          # OpenCV's per-image row limit for multi-image train sets
+MODE_ALL, MODE_MIN_DIST, MODE_RATIO = 0, 1, 2
+
+
+def as_descriptors(a) -> np.ndarray:
+    """Coerce a descriptor matrix to C-contiguous (n,32) uint8.
+
+    Accepts what ``Frame.get_descriptors`` produces (``primitives.py:200-205``),
+    including the n == 0 case, which numpy turns into a float64 ``(0,)`` array."""
+    a = np.asarray(a)
+    if a.size == 0:
+        return np.zeros((0, DESC_BYTES), np.uint8)
+    if a.dtype != np.uint8:
+        raise ValueError(f"descriptors must be uint8, got {a.dtype}")
+    if a.ndim != 2 or a.shape[1] != DESC_BYTES:
+        raise ValueError(f"descriptors must have shape (n, {DESC_BYTES}), got {a.shape}")
+    return np.ascontiguousarray(a)
+
+
+class DeviceDescriptors:
+    """A descriptor matrix resident in HBM: (n,32) uint8, row-major, 16-B aligned."""
+
+    def __init__(self, ctx: Context, host: Optional[np.ndarray] = None, rows: Optional[int] = None):
+        self.ctx = ctx
+        if host is not None:
+            host = as_descriptors(host)
+            rows = host.shape[0]
+        self.rows = int(rows or 0)
+        self.buf = ctx.malloc(max(self.rows, 1) * DESC_BYTES)
+        if host is not None and self.rows:
+            self.buf.upload(host)
+
+    def rows_view(self, start: int, stop: int) -> DeviceBuffer:
+        return self.buf.view(start * DESC_BYTES, (stop - start) * DESC_BYTES)
+
+    def free(self) -> None:
+        self.buf.free()
+
+
+class Top2Table:
+    """Device tables idx/dist int32 [rows,2] written by the top-2 kernel."""
+
+    def __init__(self, ctx: Context, rows: int):
+        self.ctx = ctx
+        self.rows = int(rows)
+        self.idx = ctx.malloc(max(self.rows, 1) * 8)
+        self.dist = ctx.malloc(max(self.rows, 1) * 8)
+
+    def download(self) -> Tuple[np.ndarray, np.ndarray]:
+        if self.rows == 0:
+            return np.zeros((0, 2), np.int32), np.zeros((0, 2), np.int32)
+        return self.idx.download(np.int32, (self.rows, 2)), self.dist.download(np.int32, (self.rows, 2))
+
+    def free(self) -> None:
+        self.idx.free()
+        self.dist.free()
+
+
+def knn2_device(ctx: Context, query: DeviceBuffer, n: int, train: DeviceBuffer, m: int, out_idx: DeviceBuffer,
+                out_dist: DeviceBuffer, train_base: int = 0) -> None:
+    """Launch the top-2 search on device-resident rows (asynchronous on the ctx stream)."""
+    check(ctx.lib.slam_bf_knn2_u256(ctx.handle, query.ptr, n, train.ptr, m, train_base, out_idx.ptr, out_dist.ptr))
+
+
+def knn_match_arrays(query, train, k: int = 2, ctx: Optional[Context] = None) -> Tuple[np.ndarray, np.ndarray]:
+    """``knnMatch(query, train, k)`` as arrays: (idx, dist) int32 [N,k], k in {1,2}.
+
+    Missing neighbours (M < k) are (-1, INT32_MAX)."""
+    if k not in (1, 2):
+        raise ValueError("k must be 1 or 2")
+    q, t = as_descriptors(query), as_descriptors(train)
+    ctx = ctx or default_context()
+    n, m = q.shape[0], t.shape[0]
+    idx = np.empty((n, 2), np.int32)
+    dist = np.empty((n, 2), np.int32)
+    if n:
+        check(ctx.lib.slam_bf_knn2_u256_host(ctx.handle, q.ctypes.data, n, t.ctypes.data if m else None, m,
+                                             idx.ctypes.data, dist.ctypes.data))
+    return np.ascontiguousarray(idx[:, :k]), np.ascontiguousarray(dist[:, :k])
+
+
+def _filter_device(ctx: Context, table: Top2Table, mode: int, param: float) -> Tuple[np.ndarray, int]:
+    keep = ctx.malloc(max(table.rows, 1))
+    cnt = ctypes.c_int64(0)
+    mind = ctypes.c_int32(0)
+    try:
+        check(ctx.lib.slam_bf_match_filter(ctx.handle, table.idx.ptr, table.dist.ptr, table.rows, mode, float(param),
+                                           keep.ptr, ctypes.byref(cnt), ctypes.byref(mind)))
+        k = keep.download(np.uint8, (table.rows,)).astype(bool) if table.rows else np.zeros(0, bool)
+    finally:
+        keep.free()
+    assert int(k.sum()) == cnt.value
+    return k, mind.value
+
+
+def match_arrays(source, query, dist_threshold: Optional[float] = None, ctx: Optional[Context] = None):
+    """``BruteForceFeatureMatcher.match`` as arrays (``feature_matchers.py:36-44``).
+
+    Note the reference's argument order: first the train ("source", last frame)
+    descriptors, then the query (current frame).  Returns (queryIdx, trainIdx,
+    distance float32), one entry per match, ascending queryIdx; the
+    ``dist_threshold`` filter keeps ``distance < max(2*min_dist, dist_threshold)``."""
+    q, t = as_descriptors(query), as_descriptors(source)
+    ctx = ctx or default_context()
+    n, m = q.shape[0], t.shape[0]
+    if n == 0 or m == 0:
+        return np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0, np.float32)
+    dq, dt = DeviceDescriptors(ctx, q), DeviceDescriptors(ctx, t)
+    table = Top2Table(ctx, n)
+    try:
+        knn2_device(ctx, dq.buf, n, dt.buf, m, table.idx, table.dist)
+        mode = MODE_MIN_DIST if dist_threshold else MODE_ALL   # `if dist_threshold and ...` (feature_matchers.py:41)
+        keep, _ = _filter_device(ctx, table, mode, float(dist_threshold or 0.0))
+        idx, dist = table.download()
+    finally:
+        table.free()
+        dq.free()
+        dt.free()
+    qi = np.nonzero(keep)[0].astype(np.int32)
+    return qi, idx[keep, 0], dist[keep, 0].astype(np.float32)
+
+
+def ratio_test_arrays(query, train, ratio: float = 0.75, ctx: Optional[Context] = None):
+    """knn=2 + Lowe ratio test: (queryIdx, trainIdx, distance) of queries with d0 < ratio * d1."""
+    q, t = as_descriptors(query), as_descriptors(train)
+    ctx = ctx or default_context()
+    n, m = q.shape[0], t.shape[0]
+    if n == 0 or m == 0:
+        return np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0, np.float32)
+    dq, dt = DeviceDescriptors(ctx, q), DeviceDescriptors(ctx, t)
+    table = Top2Table(ctx, n)
+    try:
+        knn2_device(ctx, dq.buf, n, dt.buf, m, table.idx, table.dist)
+        keep, _ = _filter_device(ctx, table, MODE_RATIO, ratio)
+        idx, dist = table.download()
+    finally:
+        table.free()
+        dq.free()
+        dt.free()
+    qi = np.nonzero(keep)[0].astype(np.int32)
+    return qi, idx[keep, 0], dist[keep, 0].astype(np.float32)
+
+
+def cross_check_arrays(query, train, ctx: Optional[Context] = None):
+    """``cv2.BFMatcher(NORM_HAMMING, crossCheck=True).match(query, train)`` as arrays."""
+    q, t = as_descriptors(query), as_descriptors(train)
+    ctx = ctx or default_context()
+    n, m = q.shape[0], t.shape[0]
+    if n == 0 or m == 0:
+        return np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0, np.float32)
+    dq, dt = DeviceDescriptors(ctx, q), DeviceDescriptors(ctx, t)
+    rev = Top2Table(ctx, m)
+    oi, od = ctx.malloc(n * 4), ctx.malloc(n * 4)
+    cnt = ctypes.c_int64(0)
+    try:
+        knn2_device(ctx, dt.buf, m, dq.buf, n, rev.idx, rev.dist)   # reverse search: train rows as queries
+        check(ctx.lib.slam_bf_cross_check(ctx.handle, rev.idx.ptr, rev.dist.ptr, m, n, oi.ptr, od.ptr,
+                                          ctypes.byref(cnt)))
+        idx = oi.download(np.int32, (n,))
+        dist = od.download(np.int32, (n,))
+    finally:
+        for b in (oi, od):
+            b.free()
+        rev.free()
+        dq.free()
+        dt.free()
+    keep = idx >= 0
+    return np.nonzero(keep)[0].astype(np.int32), idx[keep], dist[keep].astype(np.float32)
+
+
+def split_image_index(global_idx: np.ndarray, image_rows: Sequence[int]) -> Tuple[np.ndarray, np.ndarray]:
+    """Global train row -> (imgIdx, trainIdx) for a concatenated multi-image train set."""
+    offsets = np.concatenate([[0], np.cumsum(np.asarray(image_rows, np.int64))])
+    g = np.asarray(global_idx, np.int64)
+    img = np.searchsorted(offsets, g, side="right") - 1
+    local = g - offsets[np.clip(img, 0, len(offsets) - 1)]
+    none = g < 0
+    return np.where(none, -1, img).astype(np.int32), np.where(none, -1, local).astype(np.int32)
+
+
+def knn_match_collection(query, train_images: Sequence[np.ndarray], k: int = 2, ctx: Optional[Context] = None):
+    """knnMatch against a collection of train images (``BFMatcher.add``): loop-closure layout.
+
+    Returns (imgIdx, trainIdx, dist) int32 [N,k]; order (dist, imgIdx, trainIdx) as OpenCV."""
+    imgs = [as_descriptors(t) for t in train_images]
+    rows = [t.shape[0] for t in imgs]
+    if any(r >= (1 << IMGIDX_SHIFT) for r in rows):
+        raise ValueError("each train image must have fewer than 2^18 rows (OpenCV IMGIDX_ONE)")
+    cat = np.concatenate(imgs, 0) if imgs else np.zeros((0, DESC_BYTES), np.uint8)
+    idx, dist = knn_match_arrays(query, cat, k, ctx)
+    img, local = split_image_index(idx, rows)
+    return img, local, dist

@@ -1,0 +1,182 @@
+"""GPU parity: HIP top-2 / filters through the C ABI vs the CPU oracle, bit-exact."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(n, seed):
+    return np.random.default_rng(seed).integers(0, 256, (n, 32), dtype=np.uint8)
+
+
+@pytest.mark.parametrize("n,m", [(1, 1), (1, 2), (2, 1), (63, 65), (64, 64), (65, 63), (200, 200), (257, 511),
+                                 (1000, 3), (3, 1000), (513, 2049), (4096, 4096)])
+def test_knn2_matches_oracle(gpu_ctx, n, m):
+    import slamhip
+    from oracle import oracle
+
+    q, t = _rand(n, 228), _rand(m, 229)
+    idx, dist = slamhip.knn_match_arrays(q, t, 2)
+    ridx, rdist = oracle.bf_knn_c(q, t, 2, threads=8)
+    assert np.array_equal(idx, ridx)
+    assert np.array_equal(dist, rdist)
+
+
+@pytest.mark.parametrize("R", [1, 2, 4, 8])
+@pytest.mark.parametrize("bpc", [1, 4, 16])
+def test_every_kernel_variant(gpu_ctx, R, bpc):
+    """Force each queries-per-lane variant and grid split; all must agree with the oracle."""
+    import slamhip
+    from oracle import oracle
+
+    lib = slamhip.load()
+    q, t = _rand(1500, 1), _rand(2300, 2)
+    t[100:140] = t[7]          # 41-way tie on one row
+    q[3] = t[7]
+    try:
+        assert lib.slam_bf_set_tuning(R, bpc) == 0
+        idx, dist = slamhip.knn_match_arrays(q, t, 2)
+    finally:
+        lib.slam_bf_set_tuning(0, 0)
+    ridx, rdist = oracle.bf_knn_c(q, t, 2, threads=8)
+    assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist)
+    assert idx[3].tolist() == [7, 100] and dist[3].tolist() == [0, 0]
+
+
+def test_all_ties_and_extremes(gpu_ctx):
+    import slamhip
+    from oracle import oracle
+
+    q = np.zeros((130, 32), np.uint8)
+    t = np.zeros((700, 32), np.uint8)             # every distance 0: indices must be 0 and 1
+    idx, dist = slamhip.knn_match_arrays(q, t, 2)
+    assert (idx == [0, 1]).all() and (dist == 0).all()
+    t[:] = 0xFF                                    # every distance 256
+    idx, dist = slamhip.knn_match_arrays(q, t, 2)
+    assert (idx == [0, 1]).all() and (dist == 256).all()
+    # descending distances: every new row improves -> update path taken on every step
+    t = np.zeros((257, 32), np.uint8)
+    bits = np.unpackbits(t, axis=1)
+    for i in range(257):
+        bits[i, : 256 - i] = 1
+    t = np.packbits(bits, axis=1)
+    idx, dist = slamhip.knn_match_arrays(q, t, 2)
+    ridx, rdist = oracle.bf_knn_c(q, t, 2)
+    assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist)
+    assert idx[0].tolist() == [256, 255] and dist[0].tolist() == [0, 1]
+
+
+def test_empty_inputs(gpu_ctx):
+    import slamhip
+
+    q = _rand(5, 1)
+    idx, dist = slamhip.knn_match_arrays(q, np.zeros((0, 32), np.uint8), 2)
+    assert (idx == -1).all() and (dist == 2**31 - 1).all()
+    idx, dist = slamhip.knn_match_arrays(np.zeros((0, 32), np.uint8), q, 2)
+    assert idx.shape == (0, 2)
+    # Frame.get_descriptors() of an empty frame: float64 (0,) (primitives.py:200-205)
+    assert slamhip.match_arrays(np.array([]), q)[0].shape == (0,)
+    assert slamhip.match_arrays(q, np.array([]))[0].shape == (0,)
+
+
+def test_m1_gives_single_neighbour(gpu_ctx):
+    import slamhip
+
+    idx, dist = slamhip.knn_match_arrays(_rand(10, 3), _rand(1, 4), 2)
+    assert (idx[:, 0] == 0).all() and (idx[:, 1] == -1).all() and (dist[:, 1] == 2**31 - 1).all()
+
+
+@pytest.mark.parametrize("thr", [None, 0.0, 30.0, 90.0, 120.0, 400.0])
+def test_match_dropin_vs_oracle(gpu_ctx, thr):
+    """BruteForceFeatureMatcher.match(source, query, dist_threshold) == feature_matchers.py:36-44."""
+    from feature_matchers import BruteForceFeatureMatcher
+    from oracle import oracle
+
+    src, qry = _rand(300, 10), _rand(210, 11)
+    qry[5] = src[17]
+    qry[6] = src[17] ^ np.uint8(1)
+    ms = BruteForceFeatureMatcher(norm_type=6).match(src, qry, thr)
+    oq, ot, od = oracle.bf_match_c(src, qry, thr)
+    assert [m.queryIdx for m in ms] == oq.tolist()
+    assert [m.trainIdx for m in ms] == ot.tolist()
+    assert [m.distance for m in ms] == od.tolist()
+    assert all(m.imgIdx == 0 for m in ms)
+
+
+def test_ratio_and_cross_check(gpu_ctx):
+    import slamhip
+    from oracle import oracle
+
+    t = _rand(900, 20)
+    q = _rand(800, 21)
+    # planted near-duplicates so the ratio test keeps something
+    rng = np.random.default_rng(5)
+    for i in range(0, 800, 7):
+        row = t[rng.integers(0, 900)].copy()
+        row[rng.integers(0, 32)] ^= np.uint8(1 << rng.integers(0, 8))
+        q[i] = row
+    qi, ti, d = slamhip.ratio_test_arrays(q, t, 0.75)
+    ridx, rdist = oracle.bf_knn_c(q, t, 2)
+    keep = oracle.bf_ratio_c(ridx, rdist, 0.75)
+    assert keep.sum() > 50
+    assert np.array_equal(qi, np.nonzero(keep)[0]) and np.array_equal(ti, ridx[keep, 0])
+    assert np.array_equal(d, rdist[keep, 0].astype(np.float32))
+    qi, ti, d = slamhip.cross_check_arrays(q, t)
+    oi, od = oracle.bf_cross_check_c(q, t)
+    k = oi >= 0
+    assert np.array_equal(qi, np.nonzero(k)[0]) and np.array_equal(ti, oi[k]) and np.array_equal(d, od[k].astype(np.float32))
+
+
+def test_collection_matches_opencv_multi_image_order(gpu_ctx):
+    import slamhip
+    from oracle import oracle
+
+    imgs = [_rand(r, 100 + i) for i, r in enumerate([300, 1, 0, 257, 512])]
+    q = _rand(333, 99)
+    imgs[3][4] = imgs[0][9]     # same row in two images: lower imgIdx wins
+    q[0] = imgs[0][9]
+    img, tr, dist = slamhip.knn_match_collection(q, imgs, 2)
+    rimg, rtr, rdist = oracle.bf_knn_multi_c(q, imgs, 2)
+    assert np.array_equal(img, rimg) and np.array_equal(tr, rtr) and np.array_equal(dist, rdist)
+    assert img[0].tolist() == [0, 3] and tr[0].tolist() == [9, 4]
+
+
+def test_full_size_properties_64k(gpu_ctx):
+    """BASELINE size 65536 x 65536: size-independent properties instead of the (slow) oracle."""
+    import slamhip
+
+    ctx = gpu_ctx
+    q, t = _rand(65536, 228), _rand(65536, 229)
+    perm = np.random.default_rng(7).permutation(65536)
+    q[:4096] = t[perm[:4096]]                       # planted exact copies: 1-NN must be (copy, 0)
+    dq, dt = slamhip.DeviceDescriptors(ctx, q), slamhip.DeviceDescriptors(ctx, t)
+    tab = slamhip.Top2Table(ctx, 65536)
+    slamhip.knn2_device(ctx, dq.buf, 65536, dt.buf, 65536, tab.idx, tab.dist)
+    idx, dist = tab.download()
+    assert (dist[:4096, 0] == 0).all() and np.array_equal(idx[:4096, 0], perm[:4096].astype(np.int32))
+    assert (dist[:, 0] <= dist[:, 1]).all()
+    tie = dist[:, 0] == dist[:, 1]
+    assert (idx[tie, 0] < idx[tie, 1]).all()        # (distance, index) order
+    # reported distances are the true distances of the reported rows
+    for col in (0, 1):
+        d = np.bitwise_count(q ^ t[idx[:, col]]).sum(1)
+        assert np.array_equal(d, dist[:, col])
+    # a random slice of queries checked exhaustively against the oracle
+    from oracle import oracle
+    sel = np.random.default_rng(8).choice(65536, 512, replace=False)
+    ridx, rdist = oracle.bf_knn_c(q[sel], t, 2, threads=8)
+    assert np.array_equal(idx[sel], ridx) and np.array_equal(dist[sel], rdist)
+    # sharded (query halves, train halves + merge) == monolithic
+    lib = ctx.lib
+    parts_i, parts_d = ctx.malloc(2 * 65536 * 8), ctx.malloc(2 * 65536 * 8)
+    for g in range(2):
+        slamhip.knn2_device(ctx, dq.buf, 65536, dt.rows_view(g * 32768, (g + 1) * 32768), 32768,
+                            parts_i.view(g * 65536 * 8), parts_d.view(g * 65536 * 8), train_base=g * 32768)
+    out = slamhip.Top2Table(ctx, 65536)
+    assert lib.slam_bf_merge_top2(ctx.handle, parts_i.ptr, parts_d.ptr, 2, 65536, out.idx.ptr, out.dist.ptr) == 0
+    midx, mdist = out.download()
+    assert np.array_equal(midx, idx) and np.array_equal(mdist, dist)
+    for b in (parts_i, parts_d):
+        b.free()
+    for o in (out, tab, dq, dt):
+        o.free()
