@@ -13,15 +13,24 @@
 //     16 VALU ops per 256-bit pair, the floor for this ISA without MFMA.
 //   * top-2 maintenance is filtered: each accumulator starts at
 //     2^31 - (current 2nd-best distance), so "some query of this lane improved"
-//     is one unsigned min-tree + one compare per R pairs; the wave skips the
-//     update block with a ballot-style exec branch (s_and_saveexec /
-//     s_cbranch_execz) when no lane improved.  The update itself is
+//     is one unsigned min-tree + one compare per R pairs, and the wave takes the
+//     update block only when the ballot of that compare is non-zero (a
+//     wave-uniform branch laid out as the unlikely path).  The update itself is
 //     branch-free on packed keys (dist << 23 | train index): 2nd = med3,
 //     1st = min, which keeps OpenCV's (distance asc, index asc) order because
 //     keys are unique and compare lexicographically.
-//   * the train axis is split into chunks (grid.y) so small and large N both
-//     fill 256 CUs; partial top-2 keys go to a workspace and a second tiny
+//   * the train axis is split into chunks (grid.y) so any N fills 256 CUs and
+//     finished waves are replaced until the end (a lone wave per SIMD issues at
+//     under half rate).  Blocks that scan different chunks for the same queries
+//     exchange their 2nd-best distance through a per-query bound in global
+//     memory (atomicMin + relaxed agent-scope load once per tile), so a chunk
+//     does not start from an infinite threshold; a stale bound is only looser,
+//     never wrong.  Partial top-2 keys go to a workspace and a second tiny
 //     kernel merges and decodes them to (int32 idx, int32 dist).
+// Measured VALU issue costs on gfx950 (tools/ubench/valu_rate.hip): v_xor 2
+// cycles per wave64, v_bcnt / v_min / v_med3 / v_cmp / shifts 4 cycles, so a
+// pair costs >= 8*2 + 8*4 = 48 SIMD cycles; SGPR or DPP operands make v_xor a
+// 4-cycle op, which is why train rows come from LDS into VGPRs.
 #include "internal.h"
 #include <stdio.h>
 
@@ -78,14 +87,34 @@ __device__ __forceinline__ void step(const u32 (&q)[R][8], const uint4 a, const 
     for (int r = 0; r < R; r++) acc[r] = bcnt_acc(q[r][6] ^ b.z, acc[r]);
 #pragma unroll
     for (int r = 0; r < R; r++) acc[r] = bcnt_acc(q[r][7] ^ b.w, acc[r]);
-    // acc[r] = 2^31 - d2[r] + d  =>  d < d2[r]  <=>  acc[r] < 2^31
-    if (min_all<R>(acc) < SLAM_ACC_BIAS) {
+    // acc[r] = 2^31 - th[r] + d  =>  d < th[r]  <=>  acc[r] < 2^31
+    if (__builtin_expect(__ballot(min_all<R>(acc) < SLAM_ACC_BIAS) != 0ull, 0)) {
 #pragma unroll
         for (int r = 0; r < R; r++) {
             u32 key = ((acc[r] - init[r]) << SLAM_KEY_IDX_BITS) | train_idx;
             b2[r] = umed3(b1[r], b2[r], key);   // second smallest of {b1, b2, key}
             b1[r] = min(b1[r], key);
-            init[r] = SLAM_ACC_BIAS - (b2[r] >> SLAM_KEY_IDX_BITS);
+            // tighten only: the threshold may already hold a smaller bound learnt from other chunks
+            init[r] = max(init[r], SLAM_ACC_BIAS - (b2[r] >> SLAM_KEY_IDX_BITS));
+        }
+    }
+}
+
+// Exchange the 2nd-best distance of the lane's queries with the blocks scanning other train chunks.
+// bound[q] only ever holds the 2nd-best distance over some subset of the train rows, i.e. an upper
+// bound of the final 2nd-best distance g: rows with d > g can be dropped, rows with d == g must stay
+// (they may win the tie on index), hence the "+ 1".  The load may be stale; that only loosens it.
+template <int R>
+__device__ __forceinline__ void share_bound(u32* __restrict__ bound, int qbase, int N, const u32 (&b2)[R],
+                                            u32 (&init)[R]) {
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int qi = qbase + r * 64;
+        if (qi < N) {
+            const u32 g = __hip_atomic_load(&bound[qi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const u32 own = b2[r] >> SLAM_KEY_IDX_BITS;
+            if (own < g) atomicMin(&bound[qi], own);
+            init[r] = SLAM_ACC_BIAS - min(own, g + 1);
         }
     }
 }
@@ -96,7 +125,7 @@ __device__ __forceinline__ void step(const u32 (&q)[R][8], const uint4 a, const 
 template <int R>
 __global__ __launch_bounds__(256) void bf_top2_kernel(const uint4* __restrict__ q, int N,
                                                       const uint4* __restrict__ t, int M, int chunk,
-                                                      uint2* __restrict__ partial) {
+                                                      uint2* __restrict__ partial, u32* __restrict__ bound) {
     __shared__ uint4 tile[2][SLAM_TILE_ROWS * 2];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -142,18 +171,23 @@ __global__ __launch_bounds__(256) void bf_top2_kernel(const uint4* __restrict__ 
                 nxt[i] = g < 2 * t1 ? t[(size_t)g] : make_uint4(0, 0, 0, 0);
             }
         }
+        share_bound<R>(bound, qbase, N, b2, init);
         const int cnt = __builtin_amdgcn_readfirstlane(min(SLAM_TILE_ROWS, t1 - tb));
         const uint4* tp = tile[buf];
+        // software pipeline: the row after next is read from LDS while the current one is computed
+        // (the last prefetch wraps inside the tile and is discarded)
         int j = 0;
+        uint4 a0 = tp[0], c0 = tp[1];
         for (; j + 2 <= cnt; j += 2) {
-            const uint4 a0 = tp[2 * j], c0 = tp[2 * j + 1];
             const uint4 a1 = tp[2 * j + 2], c1 = tp[2 * j + 3];
             step<R>(qr, a0, c0, (u32)(tb + j), b1, b2, init);
+            a0 = tp[(2 * j + 4) & (2 * SLAM_TILE_ROWS - 1)];
+            c0 = tp[(2 * j + 5) & (2 * SLAM_TILE_ROWS - 1)];
             step<R>(qr, a1, c1, (u32)(tb + j + 1), b1, b2, init);
         }
         if (j < cnt) {
-            const uint4 a0 = tp[2 * j], c0 = tp[2 * j + 1];
-            step<R>(qr, a0, c0, (u32)(tb + j), b1, b2, init);
+            const uint4 x0 = tp[2 * j], y0 = tp[2 * j + 1];
+            step<R>(qr, x0, y0, (u32)(tb + j), b1, b2, init);
         }
         if (nb < t1) {
 #pragma unroll
@@ -250,13 +284,15 @@ extern "C" int slam_bf_set_tuning(int R, int blocks_per_cu) {
 
 static bf_plan make_plan(const slam_ctx* ctx, int64_t N, int64_t M) {
     bf_plan p;
-    const int64_t target = (int64_t)ctx->num_cu * (g_blocks_per_cu ? g_blocks_per_cu : 4);
+    // 32 blocks per CU = 4 rounds at the 8 waves/SIMD the R=2 kernel runs at: enough rounds that the
+    // under-occupied tail is short, few enough that the partial tables stay small
+    const int64_t target = (int64_t)ctx->num_cu * (g_blocks_per_cu ? g_blocks_per_cu : 32);
     const int64_t max_chunks = (M + SLAM_TILE_ROWS - 1) / SLAM_TILE_ROWS;
-    // largest R whose grid can still reach the target block count
-    int R = 8;
+    // R = 2 queries per lane measured fastest at 64k x 64k (52 VGPRs, 8 waves/SIMD); small query sets
+    // drop to R = 1 to get more query blocks.  R = 4 / 8 stay available through slam_bf_set_tuning.
+    int R = 2;
     if (g_force_R) R = g_force_R;
-    else
-        while (R > 1 && ((N + 256 * R - 1) / (256 * R)) * max_chunks < target) R >>= 1;
+    else if (((N + 511) / 512) * max_chunks < (int64_t)ctx->num_cu * 8) R = 1;
     p.R = R;
     p.qblocks = (int)((N + 256 * R - 1) / (256 * R));
     int64_t S = (target + p.qblocks - 1) / p.qblocks;
@@ -274,16 +310,18 @@ static int bf_pass(slam_ctx* ctx, const void* d_query, int64_t N, const void* d_
                    int64_t train_base, void* ws, int32_t* d_idx, int32_t* d_dist) {
     const bf_plan p = make_plan(ctx, N, M);
     uint2* partial = (uint2*)ws;
+    u32* bound = (u32*)((char*)ws + (((uint64_t)p.S * N * sizeof(uint2) + 255) & ~255ull));
+    SLAM_HIP(hipMemsetAsync(bound, 0x7F, (size_t)N * sizeof(u32), ctx->stream));  // "no bound yet", and g + 1 cannot wrap
     const dim3 grid(p.qblocks, p.S), block(256);
     const uint4* q = (const uint4*)d_query;
     const uint4* t = (const uint4*)d_train;
     SLAM_HIP(hipGetLastError());
     if (int rc = slam_prof_begin(ctx)) return rc;
     switch (p.R) {
-        case 8: bf_top2_kernel<8><<<grid, block, 0, ctx->stream>>>(q, (int)N, t, (int)M, p.chunk, partial); break;
-        case 4: bf_top2_kernel<4><<<grid, block, 0, ctx->stream>>>(q, (int)N, t, (int)M, p.chunk, partial); break;
-        case 2: bf_top2_kernel<2><<<grid, block, 0, ctx->stream>>>(q, (int)N, t, (int)M, p.chunk, partial); break;
-        default: bf_top2_kernel<1><<<grid, block, 0, ctx->stream>>>(q, (int)N, t, (int)M, p.chunk, partial); break;
+        case 8: bf_top2_kernel<8><<<grid, block, 0, ctx->stream>>>(q, (int)N, t, (int)M, p.chunk, partial, bound); break;
+        case 4: bf_top2_kernel<4><<<grid, block, 0, ctx->stream>>>(q, (int)N, t, (int)M, p.chunk, partial, bound); break;
+        case 2: bf_top2_kernel<2><<<grid, block, 0, ctx->stream>>>(q, (int)N, t, (int)M, p.chunk, partial, bound); break;
+        default: bf_top2_kernel<1><<<grid, block, 0, ctx->stream>>>(q, (int)N, t, (int)M, p.chunk, partial, bound); break;
     }
     if (int rc = slam_prof_end(ctx)) return rc;
     SLAM_HIP(hipGetLastError());
@@ -295,7 +333,7 @@ static int bf_pass(slam_ctx* ctx, const void* d_query, int64_t N, const void* d_
 
 static uint64_t partial_bytes(const slam_ctx* ctx, int64_t N, int64_t M) {
     const bf_plan p = make_plan(ctx, N, M);
-    return (uint64_t)p.S * (uint64_t)N * sizeof(uint2);
+    return (((uint64_t)p.S * (uint64_t)N * sizeof(uint2) + 255) & ~255ull) + (uint64_t)N * sizeof(u32);
 }
 
 extern "C" int slam_bf_knn2_u256(slam_ctx* ctx, const void* d_query, int64_t N, const void* d_train,

@@ -1,0 +1,120 @@
+"""Query-sharded multi-GPU matching: one process per GPU, RCCL all-gather of the per-shard top-2 rows.
+
+The reference is single-process (``slam.py:22-35``); this is the sharding of
+SURVEY.md §8e.  Every (query, train) pair is independent, so rank g searches
+query rows ``[g*per, (g+1)*per)`` against the full (replicated) train set and
+writes its rows straight into its slot of the gathered table; one
+``ncclAllGather`` over xGMI then gives every rank the complete ``[N,2]``
+result, bit-identical to the single-GPU run (no merge step is involved).
+
+The rendezvous (who is rank 0, how the 128-byte RCCL id travels) is the
+launcher's business: ``init_comm`` takes a ``bcast(bytes|None) -> bytes``
+callable, e.g. built on ``torch.distributed`` (gloo) object broadcast.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import Callable, Optional, Tuple
+
+import numpy as np
+
+from ._lib import COMM_ID_BYTES, DESC_BYTES, check
+from .device import Context, DeviceBuffer
+from .matching import DeviceDescriptors, as_descriptors, knn2_device
+
+
+@dataclass(frozen=True)
+class ShardPlan:
+    """Equal-sized query shards (RCCL all-gather needs equal counts; the tail shard is padded)."""
+
+    n_query: int
+    world: int
+
+    @property
+    def rows_per_rank(self) -> int:
+        return (self.n_query + self.world - 1) // self.world if self.world > 0 else 0
+
+    def rows(self, rank: int) -> Tuple[int, int]:
+        """[start, stop) of the real query rows owned by ``rank`` (may be empty for tail ranks)."""
+        per = self.rows_per_rank
+        start = min(rank * per, self.n_query)
+        return start, min(start + per, self.n_query)
+
+    @property
+    def padded_rows(self) -> int:
+        return self.rows_per_rank * self.world
+
+
+def init_comm(ctx: Context, rank: int, world: int, bcast: Callable[[Optional[bytes]], bytes]) -> None:
+    """Create the RCCL communicator of ``ctx``; ``bcast`` ships rank 0's unique id to everybody."""
+    ident = None
+    if rank == 0:
+        buf = ctypes.create_string_buffer(COMM_ID_BYTES)
+        check(ctx.lib.slam_comm_unique_id(buf))
+        ident = buf.raw
+    ident = bcast(ident)
+    if not isinstance(ident, (bytes, bytearray)) or len(ident) != COMM_ID_BYTES:
+        raise ValueError("bcast must return the 128-byte id produced on rank 0")
+    check(ctx.lib.slam_comm_init(ctx.handle, world, rank, ctypes.create_string_buffer(bytes(ident), COMM_ID_BYTES)))
+
+
+class ShardedMatcher:
+    """knn=2 search of a query set sharded over ``world`` GPUs against a replicated train set."""
+
+    def __init__(self, ctx: Context, rank: int, world: int, query, train):
+        self.ctx, self.rank, self.world = ctx, rank, world
+        query, train = as_descriptors(query), as_descriptors(train)
+        self.plan = ShardPlan(query.shape[0], world)
+        self.n_train = train.shape[0]
+        a, b = self.plan.rows(rank)
+        self.n_local = b - a
+        self.d_query = DeviceDescriptors(ctx, query[a:b])
+        self.d_train = DeviceDescriptors(ctx, train)       # replicated: 2 MiB at 64k rows
+        per = max(self.plan.rows_per_rank, 1)
+        self.idx_all = ctx.malloc(per * world * 8)          # gathered [world*per, 2] int32
+        self.dist_all = ctx.malloc(per * world * 8)
+        self.slot_bytes = per * 8
+        # padded tail rows of the last shards must hold "no match", not garbage
+        ctx.lib.slam_memset(ctx.handle, self.idx_all.ptr, 0xFF, self.idx_all.nbytes)
+        ctx.lib.slam_memset(ctx.handle, self.dist_all.ptr, 0x7F, self.dist_all.nbytes)
+
+    def step(self) -> None:
+        """One pass: local search into this rank's slot, then all-gather (asynchronous on the ctx stream)."""
+        ctx = self.ctx
+        off = self.rank * self.slot_bytes
+        my_idx = self.idx_all.view(off, self.slot_bytes)
+        my_dist = self.dist_all.view(off, self.slot_bytes)
+        if self.n_local:
+            knn2_device(ctx, self.d_query.buf, self.n_local, self.d_train.buf, self.n_train, my_idx, my_dist)
+        if self.world > 1:
+            check(ctx.lib.slam_comm_allgather(ctx.handle, my_idx.ptr, self.idx_all.ptr, self.slot_bytes))
+            check(ctx.lib.slam_comm_allgather(ctx.handle, my_dist.ptr, self.dist_all.ptr, self.slot_bytes))
+
+    def result(self) -> Tuple[np.ndarray, np.ndarray]:
+        n = self.plan.n_query
+        rows = self.plan.padded_rows
+        if rows == 0:
+            return np.zeros((0, 2), np.int32), np.zeros((0, 2), np.int32)
+        idx = self.idx_all.download(np.int32, (rows, 2))[:n]
+        dist = self.dist_all.download(np.int32, (rows, 2))[:n]
+        return idx, dist
+
+    def free(self) -> None:
+        for b in (self.idx_all, self.dist_all):
+            b.free()
+        self.d_query.free()
+        self.d_train.free()
+
+
+def gather_rows_host(plan: ShardPlan, shards) -> np.ndarray:
+    """Host-side statement of what the all-gather produces: concatenate equal-sized (padded) shards, trim."""
+    per = plan.rows_per_rank
+    out = []
+    for g, s in enumerate(shards):
+        s = np.asarray(s)
+        pad = per - s.shape[0]
+        if pad:
+            s = np.concatenate([s, np.full((pad,) + s.shape[1:], -1, s.dtype)], 0)
+        out.append(s)
+    return np.concatenate(out, 0)[: plan.n_query] if out else np.zeros((0, 2), np.int32)
