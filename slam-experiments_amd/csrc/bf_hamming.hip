@@ -119,14 +119,41 @@ __device__ __forceinline__ void share_bound(u32* __restrict__ bound, int qbase, 
     }
 }
 
-// grid.x = query blocks of 256*R rows, grid.y = train chunks of `chunk` rows.
-// partial[chunk][query] = (best key, second key), key = dist << 23 | train row
-// (row relative to d_train of this launch), 0xFFFFFFFF = none.
+// Per-query merge state shared by the blocks of one launch (device memory owned by the ctx).
+// Invariant between launches: best[] = ~0, bound[] = 0x7F7F7F7F, arrivals[] = 0; the last block
+// of every query block restores it after decoding, so no memset or merge kernel runs per call.
+struct bf_state {
+    unsigned long long* best;   // [N]  (1st key << 32 | 2nd key), keys = dist << 23 | train row, ~0 = none
+    u32* bound;                 // [N]  upper bound of the final 2nd-best distance (share_bound)
+    u32* arrivals;              // [query blocks]  how many chunk blocks have merged their result
+};
+
+// fold this block's (b1, b2) into best[q]: lock-free CAS loop, keys of different chunks are distinct
+__device__ __forceinline__ void merge_into_slot(unsigned long long* slot, u32 b1, u32 b2) {
+    if (b1 == SLAM_KEY_NONE) return;
+    unsigned long long old = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (true) {
+        const u32 o1 = (u32)(old >> 32), o2 = (u32)old;
+        const u32 k1 = min(o1, b1);
+        const u32 k2 = min(max(o1, b1), min(o2, b2));
+        const unsigned long long merged = ((unsigned long long)k1 << 32) | k2;
+        if (merged == old) return;
+        const unsigned long long prev = atomicCAS(slot, old, merged);
+        if (prev == old) return;
+        old = prev;
+    }
+}
+
+// grid.x = query blocks of 256*R rows, grid.y = train chunks of `chunk` rows.  Every block merges
+// its top-2 into st.best; the last block to arrive for a query block decodes (idx + train_base, dist).
 template <int R>
 __global__ __launch_bounds__(256) void bf_top2_kernel(const uint4* __restrict__ q, int N,
                                                       const uint4* __restrict__ t, int M, int chunk,
-                                                      uint2* __restrict__ partial, u32* __restrict__ bound) {
+                                                      bf_state st, int train_base, int2* __restrict__ out_idx,
+                                                      int2* __restrict__ out_dist) {
     __shared__ uint4 tile[2][SLAM_TILE_ROWS * 2];
+    __shared__ u32 s_last;
+    u32* __restrict__ bound = st.bound;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int qbase = blockIdx.x * (256 * R) + wave * (64 * R) + lane;
@@ -197,34 +224,48 @@ __global__ __launch_bounds__(256) void bf_top2_kernel(const uint4* __restrict__ 
         buf ^= 1;
     }
 
+    // ---- epilogue: merge, then the last arriver of this query block decodes ----------------------
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const int qi = qbase + r * 64;
-        if (qi < N) partial[(size_t)blockIdx.y * N + qi] = make_uint2(b1[r], b2[r]);
+        if (qi < N) merge_into_slot(&st.best[qi], b1[r], b2[r]);
     }
-}
-
-// merge S partial key tables and decode to (idx + train_base, dist)
-__global__ __launch_bounds__(256) void bf_merge_keys_kernel(const uint2* __restrict__ partial, int S, int N,
-                                                            int train_base, int2* __restrict__ idx,
-                                                            int2* __restrict__ dist) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
-    u32 b1 = SLAM_KEY_NONE, b2 = SLAM_KEY_NONE;
-    for (int s = 0; s < S; s++) {
-        const uint2 p = partial[(size_t)s * N + n];
-        b2 = umed3(b1, b2, p.x);
-        b1 = min(b1, p.x);
-        b2 = umed3(b1, b2, p.y);
-        b1 = min(b1, p.y);
+    // Arrival ticket (cdna_hip_programming.md G16, counter form): the merges above are returning
+    // agent-scope atomics, already complete when the CAS loop exits; drain, barrier, one release,
+    // one relaxed ticket.  Placement-independent: nothing relies on which XCD a block runs on.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const u32 ticket = __hip_atomic_fetch_add(&st.arrivals[blockIdx.x], 1u, __ATOMIC_RELAXED,
+                                                  __HIP_MEMORY_SCOPE_AGENT);
+        s_last = ticket == gridDim.y - 1 ? 1u : 0u;
+        if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    int2 oi, od;
-    oi.x = b1 == SLAM_KEY_NONE ? SLAM_NO_MATCH_IDX : (int)(b1 & SLAM_KEY_IDX_MASK) + train_base;
-    od.x = b1 == SLAM_KEY_NONE ? SLAM_NO_MATCH_DIST : (int)(b1 >> SLAM_KEY_IDX_BITS);
-    oi.y = b2 == SLAM_KEY_NONE ? SLAM_NO_MATCH_IDX : (int)(b2 & SLAM_KEY_IDX_MASK) + train_base;
-    od.y = b2 == SLAM_KEY_NONE ? SLAM_NO_MATCH_DIST : (int)(b2 >> SLAM_KEY_IDX_BITS);
-    idx[n] = oi;
-    dist[n] = od;
+    __syncthreads();
+    if (!s_last) return;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int qi = qbase + r * 64;
+        if (qi < N) {
+            // every contribution was made by an agent-scope atomic; read it back the same way (never from L1)
+            const unsigned long long v = __hip_atomic_load(&st.best[qi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const u32 k1 = (u32)(v >> 32), k2 = (u32)v;
+            int2 oi, od;
+            oi.x = k1 == SLAM_KEY_NONE ? SLAM_NO_MATCH_IDX : (int)(k1 & SLAM_KEY_IDX_MASK) + train_base;
+            od.x = k1 == SLAM_KEY_NONE ? SLAM_NO_MATCH_DIST : (int)(k1 >> SLAM_KEY_IDX_BITS);
+            oi.y = k2 == SLAM_KEY_NONE ? SLAM_NO_MATCH_IDX : (int)(k2 & SLAM_KEY_IDX_MASK) + train_base;
+            od.y = k2 == SLAM_KEY_NONE ? SLAM_NO_MATCH_DIST : (int)(k2 >> SLAM_KEY_IDX_BITS);
+            out_idx[qi] = oi;
+            out_dist[qi] = od;
+            // restore the between-launch invariant for these queries (all other blocks are done with them)
+            __hip_atomic_store(&st.best[qi], ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&st.bound[qi], 0x7F7F7F7Fu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (tid == 0) __hip_atomic_store(&st.arrivals[blockIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // merge G decoded tables by (dist, idx)
@@ -282,58 +323,82 @@ extern "C" int slam_bf_set_tuning(int R, int blocks_per_cu) {
     return SLAM_OK;
 }
 
-static bf_plan make_plan(const slam_ctx* ctx, int64_t N, int64_t M) {
-    bf_plan p;
-    // 32 blocks per CU = 4 rounds at the 8 waves/SIMD the R=2 kernel runs at: enough rounds that the
-    // under-occupied tail is short, few enough that the partial tables stay small
-    const int64_t target = (int64_t)ctx->num_cu * (g_blocks_per_cu ? g_blocks_per_cu : 32);
-    const int64_t max_chunks = (M + SLAM_TILE_ROWS - 1) / SLAM_TILE_ROWS;
-    // R = 2 queries per lane measured fastest at 64k x 64k (52 VGPRs, 8 waves/SIMD); small query sets
-    // drop to R = 1 to get more query blocks.  R = 4 / 8 stay available through slam_bf_set_tuning.
-    int R = 2;
-    if (g_force_R) R = g_force_R;
-    else if (((N + 511) / 512) * max_chunks < (int64_t)ctx->num_cu * 8) R = 1;
-    p.R = R;
-    p.qblocks = (int)((N + 256 * R - 1) / (256 * R));
-    int64_t S = (target + p.qblocks - 1) / p.qblocks;
-    if (S > max_chunks) S = max_chunks;
+// chunks for a given R: aim at `target` blocks, but keep a chunk at two LDS tiles or more (a one-tile
+// chunk starts cold and cannot use the bound of its neighbours) unless that would leave CUs idle
+static void plan_for(const slam_ctx* ctx, int64_t N, int64_t M, int R, int64_t target, bf_plan* p) {
+    const int64_t tiles = (M + SLAM_TILE_ROWS - 1) / SLAM_TILE_ROWS;
+    p->R = R;
+    p->qblocks = (int)((N + 256 * R - 1) / (256 * R));
+    int64_t S = target / p->qblocks;
+    const int64_t two_tile = (tiles + 1) / 2;
+    if (S > two_tile) S = (int64_t)p->qblocks * two_tile >= (int64_t)ctx->num_cu * 4 ? two_tile : S;
+    if (S > tiles) S = tiles;
     if (S < 1) S = 1;
     int64_t chunk = (M + S - 1) / S;
     chunk = (chunk + SLAM_TILE_ROWS - 1) / SLAM_TILE_ROWS * SLAM_TILE_ROWS;
-    p.chunk = (int)chunk;
-    p.S = (int)((M + chunk - 1) / chunk);
+    p->chunk = (int)chunk;
+    p->S = (int)((M + chunk - 1) / chunk);
+}
+
+static bf_plan make_plan(const slam_ctx* ctx, int64_t N, int64_t M) {
+    bf_plan p;
+    // R = 1 query per lane measured fastest at every size tried (64k x 64k: 1.70 ms vs 1.79 ms for R = 2,
+    // 1.96 ms for R = 4; 42 VGPRs, 8 waves/SIMD); R = 2 / 4 / 8 stay available through slam_bf_set_tuning.
+    // 64 blocks per CU = 8 rounds at 8 waves/SIMD: finished waves keep being replaced, so the
+    // under-occupied tail (a lone wave per SIMD issues at under half rate) is short.
+    const int64_t target = (int64_t)ctx->num_cu * (g_blocks_per_cu ? g_blocks_per_cu : 64);
+    plan_for(ctx, N, M, g_force_R ? g_force_R : 1, target, &p);
     return p;
+}
+
+// merge state for up to N queries, kept clean between launches (see bf_state)
+static int bf_state_get(slam_ctx* ctx, int64_t N, bf_state* out) {
+    std::lock_guard<std::mutex> g(ctx->mu);
+    if (N > ctx->bf_state_rows) {
+        SLAM_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->bf_state_mem) SLAM_HIP(hipFree(ctx->bf_state_mem));
+        ctx->bf_state_mem = nullptr;
+        ctx->bf_state_rows = 0;
+        const int64_t rows = N + (N >> 2) + 1024;                 // headroom: slightly larger calls do not realloc
+        const size_t blocks = (size_t)(rows + 255) / 256;         // query blocks at R = 1, the finest split
+        const size_t bytes = (size_t)rows * 12 + blocks * 4;
+        SLAM_HIP(hipMalloc(&ctx->bf_state_mem, bytes));
+        char* p = (char*)ctx->bf_state_mem;
+        SLAM_HIP(hipMemsetAsync(p, 0xFF, (size_t)rows * 8, ctx->stream));
+        SLAM_HIP(hipMemsetAsync(p + (size_t)rows * 8, 0x7F, (size_t)rows * 4, ctx->stream));
+        SLAM_HIP(hipMemsetAsync(p + (size_t)rows * 12, 0, blocks * 4, ctx->stream));
+        ctx->bf_state_rows = rows;
+    }
+    char* p = (char*)ctx->bf_state_mem;
+    out->best = (unsigned long long*)p;
+    out->bound = (u32*)(p + (size_t)ctx->bf_state_rows * 8);
+    out->arrivals = (u32*)(p + (size_t)ctx->bf_state_rows * 12);
+    return SLAM_OK;
 }
 
 // one pass over at most 2^23 train rows
 static int bf_pass(slam_ctx* ctx, const void* d_query, int64_t N, const void* d_train, int64_t M,
-                   int64_t train_base, void* ws, int32_t* d_idx, int32_t* d_dist) {
+                   int64_t train_base, int32_t* d_idx, int32_t* d_dist) {
     const bf_plan p = make_plan(ctx, N, M);
-    uint2* partial = (uint2*)ws;
-    u32* bound = (u32*)((char*)ws + (((uint64_t)p.S * N * sizeof(uint2) + 255) & ~255ull));
-    SLAM_HIP(hipMemsetAsync(bound, 0x7F, (size_t)N * sizeof(u32), ctx->stream));  // "no bound yet", and g + 1 cannot wrap
+    bf_state st;
+    if (int rc = bf_state_get(ctx, N, &st)) return rc;
     const dim3 grid(p.qblocks, p.S), block(256);
     const uint4* q = (const uint4*)d_query;
     const uint4* t = (const uint4*)d_train;
+    int2* oi = (int2*)d_idx;
+    int2* od = (int2*)d_dist;
+    const int tb = (int)train_base;
     SLAM_HIP(hipGetLastError());
     if (int rc = slam_prof_begin(ctx)) return rc;
     switch (p.R) {
-        case 8: bf_top2_kernel<8><<<grid, block, 0, ctx->stream>>>(q, (int)N, t, (int)M, p.chunk, partial, bound); break;
-        case 4: bf_top2_kernel<4><<<grid, block, 0, ctx->stream>>>(q, (int)N, t, (int)M, p.chunk, partial, bound); break;
-        case 2: bf_top2_kernel<2><<<grid, block, 0, ctx->stream>>>(q, (int)N, t, (int)M, p.chunk, partial, bound); break;
-        default: bf_top2_kernel<1><<<grid, block, 0, ctx->stream>>>(q, (int)N, t, (int)M, p.chunk, partial, bound); break;
+        case 8: bf_top2_kernel<8><<<grid, block, 0, ctx->stream>>>(q, (int)N, t, (int)M, p.chunk, st, tb, oi, od); break;
+        case 4: bf_top2_kernel<4><<<grid, block, 0, ctx->stream>>>(q, (int)N, t, (int)M, p.chunk, st, tb, oi, od); break;
+        case 2: bf_top2_kernel<2><<<grid, block, 0, ctx->stream>>>(q, (int)N, t, (int)M, p.chunk, st, tb, oi, od); break;
+        default: bf_top2_kernel<1><<<grid, block, 0, ctx->stream>>>(q, (int)N, t, (int)M, p.chunk, st, tb, oi, od); break;
     }
     if (int rc = slam_prof_end(ctx)) return rc;
     SLAM_HIP(hipGetLastError());
-    bf_merge_keys_kernel<<<dim3((unsigned)((N + 255) / 256)), block, 0, ctx->stream>>>(
-        partial, p.S, (int)N, (int)train_base, (int2*)d_idx, (int2*)d_dist);
-    SLAM_HIP(hipGetLastError());
     return SLAM_OK;
-}
-
-static uint64_t partial_bytes(const slam_ctx* ctx, int64_t N, int64_t M) {
-    const bf_plan p = make_plan(ctx, N, M);
-    return (((uint64_t)p.S * (uint64_t)N * sizeof(uint2) + 255) & ~255ull) + (uint64_t)N * sizeof(u32);
 }
 
 extern "C" int slam_bf_knn2_u256(slam_ctx* ctx, const void* d_query, int64_t N, const void* d_train,
@@ -356,22 +421,16 @@ extern "C" int slam_bf_knn2_u256(slam_ctx* ctx, const void* d_query, int64_t N, 
     SLAM_REQUIRE(d_train, "slam_bf_knn2_u256: null train pointer");
     const int64_t PASS = SLAM_MAX_TRAIN_PER_PASS;
     const int64_t passes = (M + PASS - 1) / PASS;
-    if (passes == 1) {
-        void* ws = nullptr;
-        if (int rc = slam_workspace(ctx, partial_bytes(ctx, N, M), &ws)) return rc;
-        return bf_pass(ctx, d_query, N, d_train, M, train_base, ws, d_idx, d_dist);
-    }
+    if (passes == 1) return bf_pass(ctx, d_query, N, d_train, M, train_base, d_idx, d_dist);
     // train set larger than one key range: run passes into per-pass tables, then merge them
-    const uint64_t pb = partial_bytes(ctx, N, PASS);
     const uint64_t tb = (uint64_t)passes * N * 2 * sizeof(int32_t);
     void* ws = nullptr;
-    if (int rc = slam_workspace(ctx, pb + 2 * tb + 64, &ws)) return rc;
-    char* base = (char*)ws;
-    int32_t* idx_parts = (int32_t*)(base + ((pb + 15) & ~15ull));
-    int32_t* dist_parts = (int32_t*)((char*)idx_parts + tb);
+    if (int rc = slam_workspace(ctx, 2 * tb, &ws)) return rc;
+    int32_t* idx_parts = (int32_t*)ws;
+    int32_t* dist_parts = (int32_t*)((char*)ws + tb);
     for (int64_t p = 0; p < passes; p++) {
         const int64_t m0 = p * PASS, m = (M - m0) < PASS ? (M - m0) : PASS;
-        if (int rc = bf_pass(ctx, d_query, N, (const char*)d_train + m0 * SLAM_DESC_BYTES, m, train_base + m0, ws,
+        if (int rc = bf_pass(ctx, d_query, N, (const char*)d_train + m0 * SLAM_DESC_BYTES, m, train_base + m0,
                              idx_parts + p * N * 2, dist_parts + p * N * 2))
             return rc;
     }

@@ -68,6 +68,7 @@ extern "C" int slam_ctx_destroy(slam_ctx* ctx) {
     for (auto& kv : ctx->allocs) (void)hipFree(kv.first);
     if (ctx->workspace) (void)hipFree(ctx->workspace);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->bf_state_mem) (void)hipFree(ctx->bf_state_mem);
     if (ctx->prof_ev) {
         for (int i = 0; i < 2 * slam_ctx::PROF_MAX; i++) (void)hipEventDestroy(ctx->prof_ev[i]);
         delete[] ctx->prof_ev;

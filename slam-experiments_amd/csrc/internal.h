@@ -16,6 +16,8 @@ struct slam_ctx {
     void* workspace = nullptr;                      // partial top-2 tables etc.
     uint64_t workspace_bytes = 0;
     int num_cu = 0;
+    void* bf_state_mem = nullptr;                   // matcher merge state (best/bound/arrivals), clean between launches
+    int64_t bf_state_rows = 0;
     void* scratch = nullptr;                        // 4 KiB device scratch (filter counters, reductions)
     // profiling of the dominant kernel
     int prof_on = 0;

@@ -1,0 +1,54 @@
+"""GPU: the RCCL plumbing that a 1-GPU box can exercise (single-rank communicator, launcher path)."""
+import ctypes
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_single_rank_communicator_allgather_and_broadcast(gpu_ctx):
+    """dlopen(librccl) + ncclGetUniqueId + ncclCommInitRank(1 rank) + in-place all-gather / broadcast on the ctx stream."""
+    import slamhip
+    from slamhip._lib import check
+    from slamhip.dist import ShardedMatcher, init_comm
+
+    ctx = slamhip.Context(0)                     # own context: the communicator belongs to it
+    try:
+        init_comm(ctx, 0, 1, lambda ident: ident)
+        q = np.random.default_rng(1).integers(0, 256, (1000, 32), dtype=np.uint8)
+        t = np.random.default_rng(2).integers(0, 256, (3000, 32), dtype=np.uint8)
+        sm = ShardedMatcher(ctx, 0, 1, q, t)
+        sm.step()
+        check(ctx.lib.slam_comm_allgather(ctx.handle, sm.idx_all.ptr, sm.idx_all.ptr, sm.slot_bytes))
+        check(ctx.lib.slam_comm_broadcast(ctx.handle, sm.dist_all.ptr, sm.slot_bytes, 0))
+        idx, dist = sm.result()
+        ridx, rdist = slamhip.knn_match_arrays(q, t, 2)
+        assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist)
+        sm.free()
+        # calling twice is an error, not a crash
+        buf = ctypes.create_string_buffer(128)
+        assert ctx.lib.slam_comm_init(ctx.handle, 1, 0, buf) == -5
+        check(ctx.lib.slam_comm_destroy(ctx.handle))
+        assert ctx.lib.slam_comm_allgather(ctx.handle, None, None, 8) == -5   # not initialised any more
+    finally:
+        ctx.close()
+
+
+def test_bench_under_the_driver_launcher_one_rank(built):
+    """`python -m torch.distributed.run --nproc-per-node 1 bench.py --gpus 1` (the driver's launch line shape)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", "29631", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3",
+           "--warmup", "1", "--no-cpu-baseline", "--no-reproj"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 1 and rec["parity_spot_check"] is True and rec["value"] > 1e11
+    assert rec["roofline"]["kernel_ms"] > 0 and rec["unit"] == "pairs/s"
