@@ -20,6 +20,8 @@ from typing import Optional
 
 import numpy as np
 
+from slamhip import ba as _ba
+from slamhip import pose_opt as _po
 from slamhip import reproj as _r
 from slamhip.device import Context, default_context
 
@@ -66,3 +68,19 @@ class Backend:
         """Residuals and Jacobians of every observation: (e [O,2], J_pose [O,2,6], J_point [O,2,3])."""
         return _r.build_linearization(poses, points, obs_pose_idx, obs_point_idx, meas, fx, fy, cx, cy,
                                       with_point, self.ctx)
+
+    def optimize_pose(self, pose, points, meas, fx, fy, cx, cy, rounds: int = 4, iterations: int = 10):
+        """Pose-only refinement of one frame against its map points: the job of
+        ``Frontend._correct_current_pose`` (``frontend.py:298-393``) with every residual, Jacobian and
+        6x6 system evaluated on the GPU.  Returns ``slamhip.pose_opt.PoseOptResult``."""
+        return _po.optimize_pose_only(pose, points, meas, (fx, fy, cx, cy), rounds, iterations, ctx=self.ctx)
+
+    def optimize(self, poses, points, obs_pose_idx, obs_point_idx, meas, fx, fy, cx, cy, iterations: int = 10,
+                 fixed_poses=(0,), huber_delta: float = 0.0):
+        """Bundle adjustment over a window of keyframes and their landmarks (``optimizer.optimize(10)`` in
+        spirit, ``frontend.py:362``; the reference's ``Backend`` has no body, ``backend.py:101-103``).
+
+        Residuals and both Jacobian blocks of every observation are built on the GPU each iteration; the
+        reduced camera system is assembled and solved on the host.  Returns ``slamhip.ba.BAResult``."""
+        return _ba.bundle_adjust(poses, points, obs_pose_idx, obs_point_idx, meas, (fx, fy, cx, cy), iterations,
+                                 fixed_poses, huber_delta, ctx=self.ctx)

@@ -37,6 +37,7 @@
 typedef uint32_t u32;
 
 #define SLAM_TILE_ROWS 256          // train rows per LDS tile (8 KiB)
+#define SLAM_GROUP_ROWS 4           // train rows per filter test (even)
 #define SLAM_KEY_IDX_BITS 23
 #define SLAM_KEY_IDX_MASK 0x7FFFFFu
 #define SLAM_KEY_NONE 0xFFFFFFFFu
@@ -66,11 +67,11 @@ __device__ __forceinline__ u32 min_all(const u32 (&acc)[R]) {
     }
 }
 
-// one train row (a = words 0-3, b = words 4-7) against the lane's R queries
+// distances of one train row (a = words 0-3, b = words 4-7) to the lane's R queries, biased:
+// acc[r] = 2^31 - th[r] + d  =>  d < th[r]  <=>  acc[r] < 2^31 (sign bit clear)
 template <int R>
-__device__ __forceinline__ void step(const u32 (&q)[R][8], const uint4 a, const uint4 b, u32 train_idx,
-                                     u32 (&b1)[R], u32 (&b2)[R], u32 (&init)[R]) {
-    u32 acc[R];
+__device__ __forceinline__ void row_acc(const u32 (&q)[R][8], const uint4 a, const uint4 b, const u32 (&init)[R],
+                                        u32 (&acc)[R]) {
 #pragma unroll
     for (int r = 0; r < R; r++) acc[r] = bcnt_acc(q[r][0] ^ a.x, init[r]);
 #pragma unroll
@@ -87,16 +88,33 @@ __device__ __forceinline__ void step(const u32 (&q)[R][8], const uint4 a, const 
     for (int r = 0; r < R; r++) acc[r] = bcnt_acc(q[r][6] ^ b.z, acc[r]);
 #pragma unroll
     for (int r = 0; r < R; r++) acc[r] = bcnt_acc(q[r][7] ^ b.w, acc[r]);
-    // acc[r] = 2^31 - th[r] + d  =>  d < th[r]  <=>  acc[r] < 2^31
-    if (__builtin_expect(__ballot(min_all<R>(acc) < SLAM_ACC_BIAS) != 0ull, 0)) {
+}
+
+// Filter + update for U consecutive train rows.  "Some pair of this lane improved" <=> the AND of
+// all U*R accumulators has its sign bit clear: v_and_b32 is a 2-cycle op where v_min/v_cmp are 4,
+// and one compare + one wave-uniform branch (on the ballot, update block laid out as unlikely)
+// serves U rows.  The thresholds stay fixed inside a group, which only makes them looser.
+template <int R, int U>
+__device__ __forceinline__ void filter_update(const u32 (&acc)[U][R], u32 first_train_idx, u32 (&b1)[R],
+                                              u32 (&b2)[R], u32 (&init)[R]) {
+    u32 m = acc[0][0];
 #pragma unroll
-        for (int r = 0; r < R; r++) {
-            u32 key = ((acc[r] - init[r]) << SLAM_KEY_IDX_BITS) | train_idx;
-            b2[r] = umed3(b1[r], b2[r], key);   // second smallest of {b1, b2, key}
-            b1[r] = min(b1[r], key);
-            // tighten only: the threshold may already hold a smaller bound learnt from other chunks
+    for (int u = 0; u < U; u++)
+#pragma unroll
+        for (int r = 0; r < R; r++)
+            if (u || r) m &= acc[u][r];
+    if (__builtin_expect(__ballot((int)m >= 0) != 0ull, 0)) {
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const u32 key = ((acc[u][r] - init[r]) << SLAM_KEY_IDX_BITS) | (first_train_idx + u);
+                b2[r] = umed3(b1[r], b2[r], key);   // second smallest of {b1, b2, key}
+                b1[r] = min(b1[r], key);
+            }
+#pragma unroll
+        for (int r = 0; r < R; r++)   // tighten only: may already hold a smaller bound learnt from other chunks
             init[r] = max(init[r], SLAM_ACC_BIAS - (b2[r] >> SLAM_KEY_IDX_BITS));
-        }
     }
 }
 
@@ -202,19 +220,29 @@ __global__ __launch_bounds__(256) void bf_top2_kernel(const uint4* __restrict__ 
         const int cnt = __builtin_amdgcn_readfirstlane(min(SLAM_TILE_ROWS, t1 - tb));
         const uint4* tp = tile[buf];
         // software pipeline: the row after next is read from LDS while the current one is computed
-        // (the last prefetch wraps inside the tile and is discarded)
+        // (the last prefetch wraps inside the tile and is discarded).  Measured: letting the compiler
+        // batch a whole group's reads behind immediate offsets is 6 % slower than this rolling form.
         int j = 0;
         uint4 a0 = tp[0], c0 = tp[1];
-        for (; j + 2 <= cnt; j += 2) {
-            const uint4 a1 = tp[2 * j + 2], c1 = tp[2 * j + 3];
-            step<R>(qr, a0, c0, (u32)(tb + j), b1, b2, init);
-            a0 = tp[(2 * j + 4) & (2 * SLAM_TILE_ROWS - 1)];
-            c0 = tp[(2 * j + 5) & (2 * SLAM_TILE_ROWS - 1)];
-            step<R>(qr, a1, c1, (u32)(tb + j + 1), b1, b2, init);
+        constexpr int U = SLAM_GROUP_ROWS;
+        constexpr int WRAP = 2 * SLAM_TILE_ROWS - 1;
+        for (; j + U <= cnt; j += U) {
+            u32 acc[U][R];
+#pragma unroll
+            for (int u = 0; u < U; u += 2) {
+                const uint4 a1 = tp[(2 * (j + u) + 2) & WRAP], c1 = tp[(2 * (j + u) + 3) & WRAP];
+                row_acc<R>(qr, a0, c0, init, acc[u]);
+                a0 = tp[(2 * (j + u) + 4) & WRAP];
+                c0 = tp[(2 * (j + u) + 5) & WRAP];
+                row_acc<R>(qr, a1, c1, init, acc[u + 1]);
+            }
+            filter_update<R, U>(acc, (u32)(tb + j), b1, b2, init);
         }
-        if (j < cnt) {
+        for (; j < cnt; j++) {
             const uint4 x0 = tp[2 * j], y0 = tp[2 * j + 1];
-            step<R>(qr, x0, y0, (u32)(tb + j), b1, b2, init);
+            u32 acc1[1][R];
+            row_acc<R>(qr, x0, y0, init, acc1[0]);
+            filter_update<R, 1>(acc1, (u32)(tb + j), b1, b2, init);
         }
         if (nb < t1) {
 #pragma unroll
