@@ -180,3 +180,35 @@ def test_full_size_properties_64k(gpu_ctx):
         b.free()
     for o in (out, tab, dq, dt):
         o.free()
+
+
+def test_loop_closure_all_to_all_1m(gpu_ctx):
+    """BASELINE configs[3]: 512 keyframes x 2048 descriptors matched all-to-all (1,048,576 x 1,048,576 pairs grid)."""
+    import slamhip
+    from oracle import oracle
+
+    kf, per = 512, 2048
+    rng = np.random.default_rng(228)
+    allrows = rng.integers(0, 256, (kf * per, 32), dtype=np.uint8)
+    images = [allrows[i * per:(i + 1) * per] for i in range(kf)]
+    img, tr, dist = slamhip.knn_match_collection(allrows, images, 2)
+    n = kf * per
+    # every descriptor finds itself first (distance 0, its own keyframe / row), then its true nearest other row
+    assert (dist[:, 0] == 0).all()
+    assert np.array_equal(img[:, 0], np.repeat(np.arange(kf), per)) and np.array_equal(tr[:, 0], np.tile(np.arange(per), kf))
+    assert (dist[:, 1] > 0).all() and (dist[:, 1] < 110).all()
+    sel = rng.choice(n, 96, replace=False)
+    rimg, rtr, rdist = oracle.bf_knn_multi_c(allrows[sel], images, 2, threads=8)
+    assert np.array_equal(img[sel], rimg) and np.array_equal(tr[sel], rtr) and np.array_equal(dist[sel], rdist)
+    # query-sharded (8 shards of 64 keyframes, what 8 GPUs would each compute) == monolithic
+    ctx = gpu_ctx
+    dall = slamhip.DeviceDescriptors(ctx, allrows)
+    tab = slamhip.Top2Table(ctx, n // 8)
+    for g in (0, 5):
+        a, b = g * (n // 8), (g + 1) * (n // 8)
+        slamhip.knn2_device(ctx, dall.rows_view(a, b), b - a, dall.buf, n, tab.idx, tab.dist)
+        sidx, sdist = tab.download()
+        simg, str_ = slamhip.split_image_index(sidx, [per] * kf)
+        assert np.array_equal(simg, img[a:b]) and np.array_equal(str_, tr[a:b]) and np.array_equal(sdist, dist[a:b])
+    tab.free()
+    dall.free()
