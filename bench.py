@@ -43,6 +43,18 @@ OPS_PER_PAIR = 16                 # 8 v_xor + 8 v_bcnt per 256-bit pair (algorit
 CYCLES_PER_PAIRSTEP = 8 * 2 + 8 * 4
 
 
+def profiled_traffic(kernel: str):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/), or None.
+
+    PMC counters cannot be collected from inside this process; the separate FETCH_SIZE / WRITE_SIZE passes
+    over this same command are summarised (with the gfx950 corrections) in profiles/r01_hbm_counters.json."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_hbm_counters.json")) as f:
+            return float(json.load(f)[kernel]["traffic_bytes"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def make_descriptors(n: int, seed: int) -> np.ndarray:
     return np.random.default_rng(seed).integers(0, 256, (n, 32), dtype=np.uint8)
 
@@ -108,7 +120,8 @@ def reproj_bench(ctx, steps: int, warmup: int) -> dict:
     return {"workload": "200 poses x 50000 points dense = 1e7 observations, e + J_pose(2x6) + J_point(2x3), f64",
             "observations_per_s": O / (ms * 1e-3), "ms_per_step": ms, "kernel_ms": kernel_ms,
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": gbs / HBM_PEAK_GBS, "traffic": None, "bytes_per_observation": bytes_per_obs}}
+                         "frac": gbs / HBM_PEAK_GBS, "traffic": profiled_traffic("reproj_rj_kernel"),
+                         "bytes_per_observation": bytes_per_obs}}
 
 
 def main() -> int:
@@ -213,7 +226,9 @@ def main() -> int:
             "parity_spot_check": ok,
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": profiled_traffic("bf_top2_kernel") if world == 1 else None,
+                "traffic_source": "profiles/r01_hbm_counters.json (rocprofv3 PMC, separate passes, N=1 launch)",
                 "kernel": "bf_top2_kernel", "kernel_ms": kernel_ms, "launches": launches,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "note": "contractual HBM figure on algorithmic bytes; the kernel is VALU-integer bound "

@@ -372,9 +372,10 @@ static bf_plan make_plan(const slam_ctx* ctx, int64_t N, int64_t M) {
     bf_plan p;
     // R = 1 query per lane measured fastest at every size tried (64k x 64k: 1.70 ms vs 1.79 ms for R = 2,
     // 1.96 ms for R = 4; 42 VGPRs, 8 waves/SIMD); R = 2 / 4 / 8 stay available through slam_bf_set_tuning.
-    // 64 blocks per CU = 8 rounds at 8 waves/SIMD: finished waves keep being replaced, so the
-    // under-occupied tail (a lone wave per SIMD issues at under half rate) is short.
-    const int64_t target = (int64_t)ctx->num_cu * (g_blocks_per_cu ? g_blocks_per_cu : 64);
+    // 32 blocks per CU = 4 rounds at 8 waves/SIMD: finished waves keep being replaced, so the
+    // under-occupied tail (a lone wave per SIMD issues at under half rate) is short, while the
+    // per-chunk bookkeeping (bound exchange, CAS merge) stays small.
+    const int64_t target = (int64_t)ctx->num_cu * (g_blocks_per_cu ? g_blocks_per_cu : 32);
     plan_for(ctx, N, M, g_force_R ? g_force_R : 1, target, &p);
     return p;
 }

@@ -72,37 +72,37 @@ class ShardedMatcher:
         self.d_query = DeviceDescriptors(ctx, query[a:b])
         self.d_train = DeviceDescriptors(ctx, train)       # replicated: 2 MiB at 64k rows
         per = max(self.plan.rows_per_rank, 1)
-        self.idx_all = ctx.malloc(per * world * 8)          # gathered [world*per, 2] int32
-        self.dist_all = ctx.malloc(per * world * 8)
-        self.slot_bytes = per * 8
-        # padded tail rows of the last shards must hold "no match", not garbage
-        ctx.lib.slam_memset(ctx.handle, self.idx_all.ptr, 0xFF, self.idx_all.nbytes)
-        ctx.lib.slam_memset(ctx.handle, self.dist_all.ptr, 0x7F, self.dist_all.nbytes)
+        self.per = per
+        # One gathered buffer, one slot per rank; a slot = that rank's idx rows [per,2] followed by its
+        # dist rows [per,2] (int32), so ONE all-gather per step moves both tables (16*per bytes per rank:
+        # 128 KiB at 64k queries / 8 GPUs — latency-bound, so fewer collectives matter more than bytes).
+        self.slot_bytes = per * 16
+        self.gathered = ctx.malloc(self.slot_bytes * world)
+        # padded tail rows of short shards must read as "no match" after the gather, not garbage
+        check(ctx.lib.slam_memset(ctx.handle, self.gathered.ptr, 0xFF, self.gathered.nbytes))
+        off = rank * self.slot_bytes
+        self.my_idx = self.gathered.view(off, per * 8)
+        self.my_dist = self.gathered.view(off + per * 8, per * 8)
 
     def step(self) -> None:
         """One pass: local search into this rank's slot, then all-gather (asynchronous on the ctx stream)."""
         ctx = self.ctx
-        off = self.rank * self.slot_bytes
-        my_idx = self.idx_all.view(off, self.slot_bytes)
-        my_dist = self.dist_all.view(off, self.slot_bytes)
         if self.n_local:
-            knn2_device(ctx, self.d_query.buf, self.n_local, self.d_train.buf, self.n_train, my_idx, my_dist)
+            knn2_device(ctx, self.d_query.buf, self.n_local, self.d_train.buf, self.n_train, self.my_idx, self.my_dist)
         if self.world > 1:
-            check(ctx.lib.slam_comm_allgather(ctx.handle, my_idx.ptr, self.idx_all.ptr, self.slot_bytes))
-            check(ctx.lib.slam_comm_allgather(ctx.handle, my_dist.ptr, self.dist_all.ptr, self.slot_bytes))
+            check(ctx.lib.slam_comm_allgather(ctx.handle, self.my_idx.ptr, self.gathered.ptr, self.slot_bytes))
 
     def result(self) -> Tuple[np.ndarray, np.ndarray]:
-        n = self.plan.n_query
-        rows = self.plan.padded_rows
-        if rows == 0:
+        n, per = self.plan.n_query, self.per
+        if self.plan.padded_rows == 0:
             return np.zeros((0, 2), np.int32), np.zeros((0, 2), np.int32)
-        idx = self.idx_all.download(np.int32, (rows, 2))[:n]
-        dist = self.dist_all.download(np.int32, (rows, 2))[:n]
-        return idx, dist
+        raw = self.gathered.download(np.int32, (self.world, 2, per, 2))      # [rank][idx|dist][row][k]
+        idx = raw[:, 0].reshape(self.world * per, 2)[:n]
+        dist = raw[:, 1].reshape(self.world * per, 2)[:n]
+        return np.ascontiguousarray(idx), np.ascontiguousarray(dist)
 
     def free(self) -> None:
-        for b in (self.idx_all, self.dist_all):
-            b.free()
+        self.gathered.free()
         self.d_query.free()
         self.d_train.free()
 

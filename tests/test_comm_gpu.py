@@ -25,8 +25,8 @@ def test_single_rank_communicator_allgather_and_broadcast(gpu_ctx):
         t = np.random.default_rng(2).integers(0, 256, (3000, 32), dtype=np.uint8)
         sm = ShardedMatcher(ctx, 0, 1, q, t)
         sm.step()
-        check(ctx.lib.slam_comm_allgather(ctx.handle, sm.idx_all.ptr, sm.idx_all.ptr, sm.slot_bytes))
-        check(ctx.lib.slam_comm_broadcast(ctx.handle, sm.dist_all.ptr, sm.slot_bytes, 0))
+        check(ctx.lib.slam_comm_allgather(ctx.handle, sm.my_idx.ptr, sm.gathered.ptr, sm.slot_bytes))
+        check(ctx.lib.slam_comm_broadcast(ctx.handle, sm.gathered.ptr, sm.slot_bytes, 0))
         idx, dist = sm.result()
         ridx, rdist = slamhip.knn_match_arrays(q, t, 2)
         assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist)
