@@ -29,6 +29,7 @@ import time
 
 import numpy as np
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: required for multi-process RCCL on this pool
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (os.path.join(ROOT, "slam-experiments_amd"), ROOT):
     if p not in sys.path:

@@ -209,3 +209,46 @@ def knn_match_collection(query, train_images: Sequence[np.ndarray], k: int = 2, 
     idx, dist = knn_match_arrays(query, cat, k, ctx)
     img, local = split_image_index(idx, rows)
     return img, local, dist
+
+
+class ResidentMatcher:
+    """Frame-to-frame matching with descriptors kept in HBM.
+
+    ``Frontend._match_features`` (``frontend.py:181-187``) matches the last frame against the current one
+    on every frame, re-stacking both descriptor matrices from per-feature rows each time
+    (``primitives.py:200-205``).  Here the train side of frame k is the query side of frame k-1:
+    each frame's descriptors are uploaded once and stay on the device for the next call."""
+
+    def __init__(self, ctx: Optional[Context] = None):
+        self.ctx = ctx or default_context()
+        self._last: Optional[DeviceDescriptors] = None
+
+    def reset(self) -> None:
+        if self._last is not None:
+            self._last.free()
+            self._last = None
+
+    def push(self, descriptors, dist_threshold: Optional[float] = None):
+        """Match ``descriptors`` (current frame, query) against the previously pushed frame (train).
+
+        Returns (queryIdx, trainIdx, distance) like ``match_arrays``, or None for the first frame."""
+        cur = DeviceDescriptors(self.ctx, as_descriptors(descriptors))
+        prev, self._last = self._last, cur
+        if prev is None:
+            return None
+        try:
+            n, m = cur.rows, prev.rows
+            if n == 0 or m == 0:
+                return np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0, np.float32)
+            table = Top2Table(self.ctx, n)
+            try:
+                knn2_device(self.ctx, cur.buf, n, prev.buf, m, table.idx, table.dist)
+                mode = MODE_MIN_DIST if dist_threshold else MODE_ALL
+                keep, _ = _filter_device(self.ctx, table, mode, float(dist_threshold or 0.0))
+                idx, dist = table.download()
+            finally:
+                table.free()
+        finally:
+            prev.free()
+        qi = np.nonzero(keep)[0].astype(np.int32)
+        return qi, idx[keep, 0], dist[keep, 0].astype(np.float32)

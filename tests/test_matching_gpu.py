@@ -212,3 +212,18 @@ def test_loop_closure_all_to_all_1m(gpu_ctx):
         assert np.array_equal(simg, img[a:b]) and np.array_equal(str_, tr[a:b]) and np.array_equal(sdist, dist[a:b])
     tab.free()
     dall.free()
+
+
+def test_resident_matcher_matches_frame_to_frame(gpu_ctx):
+    """Descriptors stay on the device between frames; results equal the stateless path (and the oracle)."""
+    import slamhip
+    from oracle import oracle
+
+    rm = slamhip.ResidentMatcher(gpu_ctx)
+    frames = [_rand(n, 300 + i) for i, n in enumerate([200, 180, 0, 150, 200])]   # slam.py:23: 200 features per frame
+    assert rm.push(frames[0]) is None
+    for prev, cur in zip(frames[:-1], frames[1:]):
+        got = rm.push(cur, 70.0)
+        exp = oracle.bf_match_c(prev, cur, 70.0)
+        assert all(np.array_equal(a, b) for a, b in zip(got, exp))
+    rm.reset()
