@@ -226,17 +226,27 @@ __global__ __launch_bounds__(256) void bf_top2_kernel(const uint4* __restrict__ 
         uint4 a0 = tp[0], c0 = tp[1];
         constexpr int U = SLAM_GROUP_ROWS;
         constexpr int WRAP = 2 * SLAM_TILE_ROWS - 1;
-        for (; j + U <= cnt; j += U) {
-            u32 acc[U][R];
+        // A block starts with no threshold of its own, so in its first tile nearly every group takes the
+        // update path; there the bound is re-read after 16, 32, 64 and 128 rows (what the sibling blocks
+        // have scanned meanwhile tightens it), later once per tile.
+        int seg_end = tb == t0 ? 16 : cnt;
+        while (true) {
+            const int lim = min(seg_end, cnt);
+            for (; j + U <= lim; j += U) {
+                u32 acc[U][R];
 #pragma unroll
-            for (int u = 0; u < U; u += 2) {
-                const uint4 a1 = tp[(2 * (j + u) + 2) & WRAP], c1 = tp[(2 * (j + u) + 3) & WRAP];
-                row_acc<R>(qr, a0, c0, init, acc[u]);
-                a0 = tp[(2 * (j + u) + 4) & WRAP];
-                c0 = tp[(2 * (j + u) + 5) & WRAP];
-                row_acc<R>(qr, a1, c1, init, acc[u + 1]);
+                for (int u = 0; u < U; u += 2) {
+                    const uint4 a1 = tp[(2 * (j + u) + 2) & WRAP], c1 = tp[(2 * (j + u) + 3) & WRAP];
+                    row_acc<R>(qr, a0, c0, init, acc[u]);
+                    a0 = tp[(2 * (j + u) + 4) & WRAP];
+                    c0 = tp[(2 * (j + u) + 5) & WRAP];
+                    row_acc<R>(qr, a1, c1, init, acc[u + 1]);
+                }
+                filter_update<R, U>(acc, (u32)(tb + j), b1, b2, init);
             }
-            filter_update<R, U>(acc, (u32)(tb + j), b1, b2, init);
+            if (lim >= cnt) break;
+            share_bound<R>(bound, qbase, N, b2, init);
+            seg_end *= 2;
         }
         for (; j < cnt; j++) {
             const uint4 x0 = tp[2 * j], y0 = tp[2 * j + 1];
@@ -351,15 +361,16 @@ extern "C" int slam_bf_set_tuning(int R, int blocks_per_cu) {
     return SLAM_OK;
 }
 
-// chunks for a given R: aim at `target` blocks, but keep a chunk at two LDS tiles or more (a one-tile
-// chunk starts cold and cannot use the bound of its neighbours) unless that would leave CUs idle
-static void plan_for(const slam_ctx* ctx, int64_t N, int64_t M, int R, int64_t target, bf_plan* p) {
+// chunks for a given R: aim at `blocks_per_cu` blocks per CU, a chunk being at least one LDS tile
+static void plan_for(const slam_ctx* ctx, int64_t N, int64_t M, int R, int blocks_per_cu, bf_plan* p) {
     const int64_t tiles = (M + SLAM_TILE_ROWS - 1) / SLAM_TILE_ROWS;
     p->R = R;
     p->qblocks = (int)((N + 256 * R - 1) / (256 * R));
-    int64_t S = target / p->qblocks;
-    const int64_t two_tile = (tiles + 1) / 2;
-    if (S > two_tile) S = (int64_t)p->qblocks * two_tile >= (int64_t)ctx->num_cu * 4 ? two_tile : S;
+    // 32 blocks per CU = 4 rounds at 8 waves/SIMD: finished waves keep being replaced, so the
+    // under-occupied tail (a lone wave per SIMD issues at under half rate) is short; query shards
+    // with fewer query blocks than CUs (multi-GPU runs) measured 3-5 % faster still with 64.
+    if (!blocks_per_cu) blocks_per_cu = p->qblocks >= ctx->num_cu ? 32 : 64;
+    int64_t S = (int64_t)ctx->num_cu * blocks_per_cu / p->qblocks;
     if (S > tiles) S = tiles;
     if (S < 1) S = 1;
     int64_t chunk = (M + S - 1) / S;
@@ -370,13 +381,9 @@ static void plan_for(const slam_ctx* ctx, int64_t N, int64_t M, int R, int64_t t
 
 static bf_plan make_plan(const slam_ctx* ctx, int64_t N, int64_t M) {
     bf_plan p;
-    // R = 1 query per lane measured fastest at every size tried (64k x 64k: 1.70 ms vs 1.79 ms for R = 2,
-    // 1.96 ms for R = 4; 42 VGPRs, 8 waves/SIMD); R = 2 / 4 / 8 stay available through slam_bf_set_tuning.
-    // 32 blocks per CU = 4 rounds at 8 waves/SIMD: finished waves keep being replaced, so the
-    // under-occupied tail (a lone wave per SIMD issues at under half rate) is short, while the
-    // per-chunk bookkeeping (bound exchange, CAS merge) stays small.
-    const int64_t target = (int64_t)ctx->num_cu * (g_blocks_per_cu ? g_blocks_per_cu : 32);
-    plan_for(ctx, N, M, g_force_R ? g_force_R : 1, target, &p);
+    // R = 1 query per lane measured fastest at every size tried (64k x 64k: 1.68 ms vs 1.79 ms for R = 2,
+    // 1.96 ms for R = 4; 54 VGPRs, 8 waves/SIMD); R = 2 / 4 / 8 stay available through slam_bf_set_tuning.
+    plan_for(ctx, N, M, g_force_R ? g_force_R : 1, g_blocks_per_cu, &p);
     return p;
 }
 
