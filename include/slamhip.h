@@ -172,6 +172,13 @@ SLAM_API int slam_comm_destroy(slam_ctx* ctx);
  * in-place allowed when d_send == d_recv + rank*bytes_per_rank. */
 SLAM_API int slam_comm_allgather(slam_ctx* ctx, const void* d_send, void* d_recv, uint64_t bytes_per_rank);
 SLAM_API int slam_comm_broadcast(slam_ctx* ctx, void* d_buf, uint64_t bytes, int root);
+/* Double-buffered form for back-to-back passes: the all-gather of result buffer `buffer_id` (0 or 1) runs on a
+ * second stream of the ctx, ordered after everything issued so far on the main stream, so the next pass (which
+ * writes the OTHER buffer) overlaps it.  slam_comm_wait_buffer makes the main stream wait until the last
+ * gather of that buffer has finished (call it before overwriting the buffer); slam_sync waits for both streams. */
+SLAM_API int slam_comm_allgather_overlapped(slam_ctx* ctx, const void* d_send, void* d_recv, uint64_t bytes_per_rank,
+                                            int buffer_id);
+SLAM_API int slam_comm_wait_buffer(slam_ctx* ctx, int buffer_id);
 
 #ifdef __cplusplus
 }

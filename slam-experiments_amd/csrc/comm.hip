@@ -77,6 +77,12 @@ extern "C" int slam_comm_init(slam_ctx* ctx, int nranks, int rank, const void* h
     ctx->comm = comm;
     ctx->comm_rank = rank;
     ctx->comm_nranks = nranks;
+    SLAM_HIP(hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
+    SLAM_HIP(hipEventCreateWithFlags(&ctx->comm_ready, hipEventDisableTiming));
+    for (int i = 0; i < 2; i++) {
+        SLAM_HIP(hipEventCreateWithFlags(&ctx->comm_done[i], hipEventDisableTiming));
+        ctx->comm_done_valid[i] = false;
+    }
     return SLAM_OK;
 }
 
@@ -85,6 +91,16 @@ extern "C" int slam_comm_destroy(slam_ctx* ctx) {
     if (!ctx->comm) return SLAM_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->comm_stream) {
+        (void)hipStreamSynchronize(ctx->comm_stream);
+        (void)hipStreamDestroy(ctx->comm_stream);
+        ctx->comm_stream = nullptr;
+    }
+    if (ctx->comm_ready) { (void)hipEventDestroy(ctx->comm_ready); ctx->comm_ready = nullptr; }
+    for (int i = 0; i < 2; i++) {
+        if (ctx->comm_done[i]) { (void)hipEventDestroy(ctx->comm_done[i]); ctx->comm_done[i] = nullptr; }
+        ctx->comm_done_valid[i] = false;
+    }
     ncclResult_t r = g_rccl.CommDestroy((ncclComm_t)ctx->comm);
     ctx->comm = nullptr;
     ctx->comm_rank = -1;
@@ -111,5 +127,32 @@ extern "C" int slam_comm_broadcast(slam_ctx* ctx, void* d_buf, uint64_t bytes, i
     SLAM_REQUIRE(d_buf, "slam_comm_broadcast: null device pointer");
     SLAM_HIP(hipSetDevice(ctx->device));
     SLAM_NCCL(g_rccl.Broadcast(d_buf, d_buf, (size_t)bytes, ncclInt8, root, (ncclComm_t)ctx->comm, ctx->stream));
+    return SLAM_OK;
+}
+
+extern "C" int slam_comm_allgather_overlapped(slam_ctx* ctx, const void* d_send, void* d_recv,
+                                              uint64_t bytes_per_rank, int buffer_id) {
+    SLAM_REQUIRE(ctx, "slam_comm_allgather_overlapped: null ctx");
+    if (!ctx->comm) return slam_set_error(SLAM_ERR_STATE, "slam_comm_allgather_overlapped: communicator not initialised");
+    SLAM_REQUIRE(buffer_id == 0 || buffer_id == 1, "buffer_id must be 0 or 1");
+    SLAM_REQUIRE(bytes_per_rank == 0 || (d_send && d_recv), "slam_comm_allgather_overlapped: null device pointer");
+    SLAM_HIP(hipSetDevice(ctx->device));
+    // comm stream starts after everything issued so far on the main stream (the search that filled d_send)
+    SLAM_HIP(hipEventRecord(ctx->comm_ready, ctx->stream));
+    SLAM_HIP(hipStreamWaitEvent(ctx->comm_stream, ctx->comm_ready, 0));
+    if (bytes_per_rank)
+        SLAM_NCCL(g_rccl.AllGather(d_send, d_recv, (size_t)bytes_per_rank, ncclInt8, (ncclComm_t)ctx->comm,
+                                   ctx->comm_stream));
+    SLAM_HIP(hipEventRecord(ctx->comm_done[buffer_id], ctx->comm_stream));
+    ctx->comm_done_valid[buffer_id] = true;
+    return SLAM_OK;
+}
+
+extern "C" int slam_comm_wait_buffer(slam_ctx* ctx, int buffer_id) {
+    SLAM_REQUIRE(ctx, "slam_comm_wait_buffer: null ctx");
+    SLAM_REQUIRE(buffer_id == 0 || buffer_id == 1, "buffer_id must be 0 or 1");
+    if (!ctx->comm || !ctx->comm_done_valid[buffer_id]) return SLAM_OK;   // nothing in flight for this buffer
+    SLAM_HIP(hipSetDevice(ctx->device));
+    SLAM_HIP(hipStreamWaitEvent(ctx->stream, ctx->comm_done[buffer_id], 0));
     return SLAM_OK;
 }

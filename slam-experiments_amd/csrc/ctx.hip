@@ -90,6 +90,7 @@ extern "C" int slam_sync(slam_ctx* ctx) {
     SLAM_REQUIRE(ctx, "slam_sync: null ctx");
     SLAM_HIP(hipSetDevice(ctx->device));
     SLAM_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->comm_stream) SLAM_HIP(hipStreamSynchronize(ctx->comm_stream));
     return SLAM_OK;
 }
 

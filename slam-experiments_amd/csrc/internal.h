@@ -27,6 +27,10 @@ struct slam_ctx {
     // RCCL
     void* comm = nullptr;                           // ncclComm_t
     int comm_rank = -1, comm_nranks = 0;
+    hipStream_t comm_stream = nullptr;              // second stream: overlapped all-gathers
+    hipEvent_t comm_ready = nullptr;                // main stream -> comm stream hand-off
+    hipEvent_t comm_done[2] = {nullptr, nullptr};   // last gather of result buffer 0 / 1
+    bool comm_done_valid[2] = {false, false};
 };
 
 int slam_set_error(int code, const char* fmt, ...);

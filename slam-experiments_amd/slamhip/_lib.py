@@ -62,6 +62,8 @@ SIGNATURES = {
     "slam_comm_destroy": (c_int, [c_void_p]),
     "slam_comm_allgather": (c_int, [c_void_p, c_void_p, c_void_p, c_uint64]),
     "slam_comm_broadcast": (c_int, [c_void_p, c_void_p, c_uint64, c_int]),
+    "slam_comm_allgather_overlapped": (c_int, [c_void_p, c_void_p, c_void_p, c_uint64, c_int]),
+    "slam_comm_wait_buffer": (c_int, [c_void_p, c_int]),
 }
 
 _lib = None

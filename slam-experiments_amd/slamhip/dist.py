@@ -73,36 +73,53 @@ class ShardedMatcher:
         self.d_train = DeviceDescriptors(ctx, train)       # replicated: 2 MiB at 64k rows
         per = max(self.plan.rows_per_rank, 1)
         self.per = per
-        # One gathered buffer, one slot per rank; a slot = that rank's idx rows [per,2] followed by its
-        # dist rows [per,2] (int32), so ONE all-gather per step moves both tables (16*per bytes per rank:
-        # 128 KiB at 64k queries / 8 GPUs — latency-bound, so fewer collectives matter more than bytes).
+        # A gathered buffer has one slot per rank; a slot = that rank's idx rows [per,2] followed by its
+        # dist rows [per,2] (int32), so ONE all-gather per pass moves both tables (16*per bytes per rank:
+        # 128 KiB at 64k queries / 8 GPUs - latency-bound, so fewer collectives matter more than bytes).
+        # Two such buffers alternate between passes: the gather of pass i runs on the ctx's second stream
+        # while the search of pass i+1 fills the other buffer.
         self.slot_bytes = per * 16
-        self.gathered = ctx.malloc(self.slot_bytes * world)
-        # padded tail rows of short shards must read as "no match" after the gather, not garbage
-        check(ctx.lib.slam_memset(ctx.handle, self.gathered.ptr, 0xFF, self.gathered.nbytes))
+        self.gathered = [ctx.malloc(self.slot_bytes * world) for _ in range(2 if world > 1 else 1)]
         off = rank * self.slot_bytes
-        self.my_idx = self.gathered.view(off, per * 8)
-        self.my_dist = self.gathered.view(off + per * 8, per * 8)
+        self.my_idx, self.my_dist = [], []
+        for g in self.gathered:
+            # padded tail rows of short shards must read as "no match" after the gather, not garbage
+            check(ctx.lib.slam_memset(ctx.handle, g.ptr, 0xFF, g.nbytes))
+            self.my_idx.append(g.view(off, per * 8))
+            self.my_dist.append(g.view(off + per * 8, per * 8))
+        self.passes = 0
+        self.last = 0
 
     def step(self) -> None:
-        """One pass: local search into this rank's slot, then all-gather (asynchronous on the ctx stream)."""
+        """One pass: local search into this rank's slot, then the all-gather of that buffer (all asynchronous)."""
         ctx = self.ctx
-        if self.n_local:
-            knn2_device(ctx, self.d_query.buf, self.n_local, self.d_train.buf, self.n_train, self.my_idx, self.my_dist)
+        b = self.passes % len(self.gathered)
         if self.world > 1:
-            check(ctx.lib.slam_comm_allgather(ctx.handle, self.my_idx.ptr, self.gathered.ptr, self.slot_bytes))
+            check(ctx.lib.slam_comm_wait_buffer(ctx.handle, b))      # the gather that last used this buffer is done
+        if self.n_local:
+            knn2_device(ctx, self.d_query.buf, self.n_local, self.d_train.buf, self.n_train, self.my_idx[b],
+                        self.my_dist[b])
+        if self.world > 1:
+            check(ctx.lib.slam_comm_allgather_overlapped(ctx.handle, self.my_idx[b].ptr, self.gathered[b].ptr,
+                                                         self.slot_bytes, b))
+        self.last = b
+        self.passes += 1
 
     def result(self) -> Tuple[np.ndarray, np.ndarray]:
+        """The complete [N,2] tables of the most recent pass (waits for both streams)."""
         n, per = self.plan.n_query, self.per
         if self.plan.padded_rows == 0:
             return np.zeros((0, 2), np.int32), np.zeros((0, 2), np.int32)
-        raw = self.gathered.download(np.int32, (self.world, 2, per, 2))      # [rank][idx|dist][row][k]
+        self.ctx.sync()
+        raw = self.gathered[self.last].download(np.int32, (self.world, 2, per, 2))   # [rank][idx|dist][row][k]
         idx = raw[:, 0].reshape(self.world * per, 2)[:n]
         dist = raw[:, 1].reshape(self.world * per, 2)[:n]
         return np.ascontiguousarray(idx), np.ascontiguousarray(dist)
 
     def free(self) -> None:
-        self.gathered.free()
+        self.ctx.sync()
+        for g in self.gathered:
+            g.free()
         self.d_query.free()
         self.d_train.free()
 

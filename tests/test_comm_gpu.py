@@ -24,12 +24,19 @@ def test_single_rank_communicator_allgather_and_broadcast(gpu_ctx):
         q = np.random.default_rng(1).integers(0, 256, (1000, 32), dtype=np.uint8)
         t = np.random.default_rng(2).integers(0, 256, (3000, 32), dtype=np.uint8)
         sm = ShardedMatcher(ctx, 0, 1, q, t)
-        sm.step()
-        check(ctx.lib.slam_comm_allgather(ctx.handle, sm.my_idx.ptr, sm.gathered.ptr, sm.slot_bytes))
-        check(ctx.lib.slam_comm_broadcast(ctx.handle, sm.gathered.ptr, sm.slot_bytes, 0))
+        sm.world = 2                                   # force the collective path of step() on the 1-rank communicator
+        sm.gathered.append(ctx.malloc(sm.slot_bytes))
+        sm.my_idx.append(sm.gathered[1].view(0, sm.per * 8))
+        sm.my_dist.append(sm.gathered[1].view(sm.per * 8, sm.per * 8))
+        for _ in range(5):                             # both buffers, wait_buffer / overlapped gather on the second stream
+            sm.step()
+        sm.world = 1
         idx, dist = sm.result()
         ridx, rdist = slamhip.knn_match_arrays(q, t, 2)
         assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist)
+        check(ctx.lib.slam_comm_allgather(ctx.handle, sm.my_idx[0].ptr, sm.gathered[0].ptr, sm.slot_bytes))
+        check(ctx.lib.slam_comm_broadcast(ctx.handle, sm.gathered[0].ptr, sm.slot_bytes, 0))
+        ctx.sync()
         sm.free()
         # calling twice is an error, not a crash
         buf = ctypes.create_string_buffer(128)
