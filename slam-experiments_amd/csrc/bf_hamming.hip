@@ -12,21 +12,25 @@
 //   * inner op per 32-bit word: v_xor_b32 + accumulating v_bcnt_u32_b32 =
 //     16 VALU ops per 256-bit pair, the floor for this ISA without MFMA.
 //   * top-2 maintenance is filtered: each accumulator starts at
-//     2^31 - (current 2nd-best distance), so "some query of this lane improved"
-//     is one unsigned min-tree + one compare per R pairs, and the wave takes the
-//     update block only when the ballot of that compare is non-zero (a
-//     wave-uniform branch laid out as the unlikely path).  The update itself is
-//     branch-free on packed keys (dist << 23 | train index): 2nd = med3,
-//     1st = min, which keeps OpenCV's (distance asc, index asc) order because
-//     keys are unique and compare lexicographically.
+//     2^31 - (current threshold), so "this pair improved" is the sign bit of
+//     the accumulator.  The accumulators of 16 consecutive train rows are
+//     AND-ed (v_and is a 2-cycle op; v_min / v_cmp are 4) and one compare + one
+//     wave-uniform branch on the ballot (update block laid out as unlikely)
+//     serves the whole group.  The update itself is branch-free on packed keys
+//     (dist << 23 | train index): 2nd = med3, 1st = min, which keeps OpenCV's
+//     (distance asc, index asc) order because keys are unique and compare
+//     lexicographically.
 //   * the train axis is split into chunks (grid.y) so any N fills 256 CUs and
 //     finished waves are replaced until the end (a lone wave per SIMD issues at
 //     under half rate).  Blocks that scan different chunks for the same queries
 //     exchange their 2nd-best distance through a per-query bound in global
-//     memory (atomicMin + relaxed agent-scope load once per tile), so a chunk
-//     does not start from an infinite threshold; a stale bound is only looser,
-//     never wrong.  Partial top-2 keys go to a workspace and a second tiny
-//     kernel merges and decodes them to (int32 idx, int32 dist).
+//     memory (atomicMin + relaxed agent-scope load per tile, more often in a
+//     block's first tile), so a chunk does not start from an infinite
+//     threshold; a stale bound is only looser, never wrong.
+//   * every block folds its top-2 into a per-query 64-bit slot with a CAS loop;
+//     the last block to arrive for a query block (agent-scope ticket) decodes
+//     the slots to (int32 idx, int32 dist) and restores the merge state, so a
+//     call is ONE kernel: no memset, no partial tables, no merge kernel.
 // Measured VALU issue costs on gfx950 (tools/ubench/valu_rate.hip): v_xor 2
 // cycles per wave64, v_bcnt / v_min / v_med3 / v_cmp / shifts 4 cycles, so a
 // pair costs >= 8*2 + 8*4 = 48 SIMD cycles; SGPR or DPP operands make v_xor a
@@ -37,7 +41,7 @@
 typedef uint32_t u32;
 
 #define SLAM_TILE_ROWS 256          // train rows per LDS tile (8 KiB)
-#define SLAM_GROUP_ROWS 4           // train rows per filter test (even)
+#define SLAM_GROUP_PAIRS 16         // (train rows) x (queries per lane) covered by one filter test
 #define SLAM_KEY_IDX_BITS 23
 #define SLAM_KEY_IDX_MASK 0x7FFFFFu
 #define SLAM_KEY_NONE 0xFFFFFFFFu
@@ -51,21 +55,7 @@ __device__ __forceinline__ u32 bcnt_acc(u32 x, u32 acc) {
     asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(acc));
     return d;
 }
-__device__ __forceinline__ u32 umin3(u32 a, u32 b, u32 c) { return min(min(a, b), c); }
 __device__ __forceinline__ u32 umed3(u32 a, u32 b, u32 c) { return max(min(a, b), min(max(a, b), c)); }
-
-template <int R>
-__device__ __forceinline__ u32 min_all(const u32 (&acc)[R]) {
-    if constexpr (R == 1) return acc[0];
-    else if constexpr (R == 2) return min(acc[0], acc[1]);
-    else if constexpr (R == 4) return min(umin3(acc[0], acc[1], acc[2]), acc[3]);
-    else {
-        static_assert(R == 8, "R must be 1, 2, 4 or 8");
-        u32 m0 = umin3(acc[0], acc[1], acc[2]);
-        u32 m1 = umin3(acc[3], acc[4], acc[5]);
-        return min(umin3(m0, m1, acc[6]), acc[7]);
-    }
-}
 
 // distances of one train row (a = words 0-3, b = words 4-7) to the lane's R queries, biased:
 // acc[r] = 2^31 - th[r] + d  =>  d < th[r]  <=>  acc[r] < 2^31 (sign bit clear)
@@ -105,13 +95,19 @@ __device__ __forceinline__ void filter_update(const u32 (&acc)[U][R], u32 first_
             if (u || r) m &= acc[u][r];
     if (__builtin_expect(__ballot((int)m >= 0) != 0ull, 0)) {
 #pragma unroll
-        for (int u = 0; u < U; u++)
+        for (int u = 0; u < U; u++) {
+            // usually one row of the group is responsible: skip the others (wave-uniform again)
+            u32 mu = acc[u][0];
+#pragma unroll
+            for (int r = 1; r < R; r++) mu &= acc[u][r];
+            if (U > 1 && __ballot((int)mu >= 0) == 0ull) continue;
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 const u32 key = ((acc[u][r] - init[r]) << SLAM_KEY_IDX_BITS) | (first_train_idx + u);
                 b2[r] = umed3(b1[r], b2[r], key);   // second smallest of {b1, b2, key}
                 b1[r] = min(b1[r], key);
             }
+        }
 #pragma unroll
         for (int r = 0; r < R; r++)   // tighten only: may already hold a smaller bound learnt from other chunks
             init[r] = max(init[r], SLAM_ACC_BIAS - (b2[r] >> SLAM_KEY_IDX_BITS));
@@ -224,7 +220,8 @@ __global__ __launch_bounds__(256) void bf_top2_kernel(const uint4* __restrict__ 
         // batch a whole group's reads behind immediate offsets is 6 % slower than this rolling form.
         int j = 0;
         uint4 a0 = tp[0], c0 = tp[1];
-        constexpr int U = SLAM_GROUP_ROWS;
+        constexpr int U = SLAM_GROUP_PAIRS / R;   // 16 rows at R = 1 (58 VGPRs, still 8 waves/SIMD)
+        static_assert(U >= 2 && U % 2 == 0, "row pipeline handles rows in pairs");
         constexpr int WRAP = 2 * SLAM_TILE_ROWS - 1;
         // A block starts with no threshold of its own, so in its first tile nearly every group takes the
         // update path; there the bound is re-read after 16, 32, 64 and 128 rows (what the sibling blocks
