@@ -227,3 +227,43 @@ def test_resident_matcher_matches_frame_to_frame(gpu_ctx):
         exp = oracle.bf_match_c(prev, cur, 70.0)
         assert all(np.array_equal(a, b) for a, b in zip(got, exp))
     rm.reset()
+
+
+def test_random_shapes_fuzz(gpu_ctx):
+    """Many odd (N, M) shapes incl. tile / wave / group boundaries, low-entropy rows (heavy ties), one context."""
+    import slamhip
+    from oracle import oracle
+
+    rng = np.random.default_rng(2026)
+    shapes = [(int(rng.integers(1, 700)), int(rng.integers(1, 1300))) for _ in range(25)]
+    shapes += [(255, 257), (256, 256), (257, 255), (64, 16), (64, 17), (1, 4097), (4097, 1), (300, 768), (513, 15)]
+    for n, m in shapes:
+        if rng.uniform() < 0.3:      # few distinct values per word -> many equal distances
+            q = rng.integers(0, 2, (n, 32), dtype=np.uint8) * 255
+            t = rng.integers(0, 2, (m, 32), dtype=np.uint8) * 255
+        else:
+            q = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+            t = rng.integers(0, 256, (m, 32), dtype=np.uint8)
+        idx, dist = slamhip.knn_match_arrays(q, t, 2)
+        ridx, rdist = oracle.bf_knn_c(q, t, 2, threads=8)
+        assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist), (n, m)
+
+
+def test_repeated_calls_keep_the_merge_state_clean(gpu_ctx):
+    """The kernel restores best/bound/arrivals itself: alternate sizes and tunings on one context, results must not drift."""
+    import slamhip
+    from oracle import oracle
+
+    lib = slamhip.load()
+    q, t = _rand(3000, 41), _rand(5000, 42)
+    ridx, rdist = oracle.bf_knn_c(q, t, 2, threads=8)
+    try:
+        for rep in range(3):
+            for R, bpc in ((1, 0), (2, 8), (1, 64), (4, 2), (8, 1)):
+                lib.slam_bf_set_tuning(R, bpc)
+                idx, dist = slamhip.knn_match_arrays(q, t, 2)
+                assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist), (rep, R, bpc)
+                small = slamhip.knn_match_arrays(q[:100], t[:77], 2)
+                assert np.array_equal(small[0], oracle.bf_knn_c(q[:100], t[:77], 2)[0])
+    finally:
+        lib.slam_bf_set_tuning(0, 0)
