@@ -267,3 +267,22 @@ def test_repeated_calls_keep_the_merge_state_clean(gpu_ctx):
                 assert np.array_equal(small[0], oracle.bf_knn_c(q[:100], t[:77], 2)[0])
     finally:
         lib.slam_bf_set_tuning(0, 0)
+
+
+def test_train_set_larger_than_one_key_range(gpu_ctx):
+    """M > 2^23 rows: the library loops passes over the train set and merges them by (dist, idx)."""
+    import slamhip
+    from oracle import oracle
+
+    m = (1 << 23) + 777
+    rng = np.random.default_rng(11)
+    t = rng.integers(0, 256, (m, 32), dtype=np.uint8)
+    q = rng.integers(0, 256, (130, 32), dtype=np.uint8)
+    q[0] = t[m - 1]                  # exact copy in the second pass
+    q[1] = t[5]
+    t[(1 << 23) + 9] = t[5]          # duplicate across the pass boundary: the lower index must come first
+    idx, dist = slamhip.knn_match_arrays(q, t, 2)
+    ridx, rdist = oracle.bf_knn_c(q, t, 2, threads=16)
+    assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist)
+    assert idx[0, 0] == m - 1 and dist[0, 0] == 0
+    assert idx[1].tolist() == [5, (1 << 23) + 9] and dist[1].tolist() == [0, 0]

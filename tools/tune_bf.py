@@ -18,8 +18,8 @@ t = np.random.default_rng(229).integers(0, 256, (m, 32), dtype=np.uint8)
 dq, dt = slamhip.DeviceDescriptors(ctx, q), slamhip.DeviceDescriptors(ctx, t)
 tab = slamhip.Top2Table(ctx, n)
 ref = None
-for R in (1,):
-    for bpc in (0, 16, 32, 64):
+for R in (1, 2, 4, 8, 1):
+    for bpc in (0, 32):
         lib.slam_bf_set_tuning(R, bpc)
         for _ in range(3):
             slamhip.knn2_device(ctx, dq.buf, n, dt.buf, m, tab.idx, tab.dist)
