@@ -15,6 +15,9 @@
  *   slam_reproj_rj_f64     EdgeProjectionPoseOnly.compute_error /
  *                          linearize_oplus (frontend.py:272-291), driven by
  *                          Frontend._correct_current_pose (frontend.py:298-393)
+ *   slam_pose_normal_eq_f64 / slam_pose_optimize_f64
+ *                          the g2o graph + LM loop of Frontend._correct_current_pose
+ *                          (frontend.py:298-393)
  *   slam_comm_*            no reference counterpart (the reference is single
  *                          process); RCCL all-gather of per-shard top-2 rows
  *
@@ -162,6 +165,17 @@ SLAM_API int slam_pose_normal_eq_f64(slam_ctx* ctx, const double* d_pose,
                             double fx, double fy, double cx, double cy,
                             double huber_delta,
                             double* d_H, double* d_b, double* d_chi2);
+
+/* The whole of Frontend._correct_current_pose (frontend.py:298-393) as one launch: `rounds` outer rounds
+ * (reference: 4) of `iterations` LM iterations (reference: 10) on one pose against O fixed points, every
+ * round restarting from d_pose_in, edges with chi2 > chi2_threshold (reference: 5.991**2) leaving the
+ * optimisation after each round, the Huber kernel (delta; reference: 1.0) dropped after round index 2.
+ * Outputs: d_pose_out [12], d_inlier uint8 [O] (1 = chi2 <= threshold at the end), d_chi2 [O],
+ * d_stats int32 [2] = {inlier count, accepted LM steps}.  Asynchronous on the ctx stream. */
+SLAM_API int slam_pose_optimize_f64(slam_ctx* ctx, const double* d_pose_in, const double* d_points,
+                                    const double* d_meas, int64_t O, double fx, double fy, double cx, double cy,
+                                    int rounds, int iterations, double chi2_threshold, double huber_delta,
+                                    double* d_pose_out, uint8_t* d_inlier, double* d_chi2, int32_t* d_stats);
 
 /* ---- multi-GPU: RCCL all-gather of per-shard result rows ---------------- */
 #define SLAM_COMM_ID_BYTES 128

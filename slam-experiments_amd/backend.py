@@ -69,11 +69,14 @@ class Backend:
         return _r.build_linearization(poses, points, obs_pose_idx, obs_point_idx, meas, fx, fy, cx, cy,
                                       with_point, self.ctx)
 
-    def optimize_pose(self, pose, points, meas, fx, fy, cx, cy, rounds: int = 4, iterations: int = 10):
+    def optimize_pose(self, pose, points, meas, fx, fy, cx, cy, rounds: int = 4, iterations: int = 10,
+                      on_device: bool = True):
         """Pose-only refinement of one frame against its map points: the job of
-        ``Frontend._correct_current_pose`` (``frontend.py:298-393``) with every residual, Jacobian and
-        6x6 system evaluated on the GPU.  Returns ``slamhip.pose_opt.PoseOptResult``."""
-        return _po.optimize_pose_only(pose, points, meas, (fx, fy, cx, cy), rounds, iterations, ctx=self.ctx)
+        ``Frontend._correct_current_pose`` (``frontend.py:298-393``).  With ``on_device`` (default) the whole
+        four-round LM loop is one kernel launch; otherwise the host drives it and the GPU evaluates every
+        residual, Jacobian and 6x6 system.  Returns ``slamhip.pose_opt.PoseOptResult``."""
+        fn = _po.optimize_pose_only_device if on_device else _po.optimize_pose_only
+        return fn(pose, points, meas, (fx, fy, cx, cy), rounds, iterations, ctx=self.ctx)
 
     def optimize(self, poses, points, obs_pose_idx, obs_point_idx, meas, fx, fy, cx, cy, iterations: int = 10,
                  fixed_poses=(0,), huber_delta: float = 0.0):

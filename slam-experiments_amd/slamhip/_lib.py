@@ -57,6 +57,9 @@ SIGNATURES = {
                                    c_int64, c_double, c_double, c_double, c_double, c_void_p, c_void_p, c_void_p]),
     "slam_pose_normal_eq_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double,
                                         c_double, c_double, c_double, c_double, c_void_p, c_void_p, c_void_p]),
+    "slam_pose_optimize_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double, c_double, c_double,
+                                       c_double, c_int, c_int, c_double, c_double, c_void_p, c_void_p, c_void_p,
+                                       c_void_p]),
     "slam_comm_unique_id": (c_int, [c_void_p]),
     "slam_comm_init": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "slam_comm_destroy": (c_int, [c_void_p]),

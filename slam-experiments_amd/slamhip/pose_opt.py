@@ -138,3 +138,46 @@ def optimize_pose_only(pose, points, meas, intrinsics, rounds: int = 4, iteratio
     finally:
         prob.free()
     return PoseOptResult(pose=T, inliers=active, chi2=chi2, n_inliers=int(active.sum()), iterations=total)
+
+
+def optimize_pose_only_device(pose, points, meas, intrinsics, rounds: int = 4, iterations: int = 10,
+                              chi2_threshold: float = CHI2_THRESHOLD, huber_delta: float = HUBER_DELTA,
+                              ctx: Optional[Context] = None) -> PoseOptResult:
+    """Same job as ``optimize_pose_only`` with the whole LM loop on the GPU: ONE kernel launch
+    (``slam_pose_optimize_f64``) instead of one launch + PCIe round trip per LM trial."""
+    import ctypes  # noqa: F401  (ctypes types come through the binding)
+
+    from ._lib import check
+
+    ctx = ctx or default_context()
+    T0 = np.eye(4)
+    P = np.asarray(pose, np.float64)
+    T0[:3, :4] = P.reshape(-1, 4)[:3, :4] if P.size != 12 else P.reshape(3, 4)
+    points = np.ascontiguousarray(points, np.float64).reshape(-1, 3)
+    meas = np.ascontiguousarray(meas, np.float64).reshape(-1, 2)
+    O = points.shape[0]
+    if meas.shape[0] != O:
+        raise ValueError("one measurement per point")
+    fx, fy, cx, cy = (float(v) for v in intrinsics)
+    o = max(O, 1)
+    bufs = []
+    try:
+        d_in = ctx.upload(T0[:3, :4].reshape(12)); bufs.append(d_in)
+        d_pts = ctx.upload(points) if O else ctx.malloc(24); bufs.append(d_pts)
+        d_meas = ctx.upload(meas) if O else ctx.malloc(16); bufs.append(d_meas)
+        d_out = ctx.malloc(96); bufs.append(d_out)
+        d_inl = ctx.malloc(o); bufs.append(d_inl)
+        d_chi2 = ctx.malloc(o * 8); bufs.append(d_chi2)
+        d_stats = ctx.malloc(8); bufs.append(d_stats)
+        check(ctx.lib.slam_pose_optimize_f64(ctx.handle, d_in.ptr, d_pts.ptr, d_meas.ptr, O, fx, fy, cx, cy, int(rounds),
+                                             int(iterations), float(chi2_threshold), float(huber_delta), d_out.ptr,
+                                             d_inl.ptr, d_chi2.ptr, d_stats.ptr))
+        T = np.eye(4)
+        T[:3, :4] = d_out.download(np.float64, (3, 4))
+        inl = d_inl.download(np.uint8, (O,)).astype(bool) if O else np.zeros(0, bool)
+        chi2 = d_chi2.download(np.float64, (O,)) if O else np.zeros(0)
+        stats = d_stats.download(np.int32, (2,))
+    finally:
+        for b in bufs:
+            b.free()
+    return PoseOptResult(pose=T, inliers=inl, chi2=chi2, n_inliers=int(stats[0]), iterations=int(stats[1]))

@@ -36,7 +36,12 @@ def test_pose_only_recovers_pose_and_rejects_outliers(gpu_ctx):
     meas[bad] += rng.uniform(40, 120, (30, 2)) * rng.choice([-1, 1], (30, 2))
     meas = meas.astype(np.int32).astype(np.float64)     # int-truncated pixels (primitives.py:110-112)
     T_init = se3_exp([0.02, -0.015, 0.01, 0.08, -0.05, 0.06]) @ T_true
-    res = Backend().optimize_pose(T_init, X, meas, FX, FY, CX, CY)
+    res = Backend().optimize_pose(T_init, X, meas, FX, FY, CX, CY, on_device=False)
+    dev = Backend().optimize_pose(T_init, X, meas, FX, FY, CX, CY, on_device=True)
+    # the one-launch device loop follows the same schedule as the host-driven one
+    assert np.allclose(dev.pose, res.pose, rtol=0, atol=1e-8) and np.array_equal(dev.inliers, res.inliers)
+    assert dev.n_inliers == res.n_inliers and abs(dev.iterations - res.iterations) <= 3   # a last negligible step may flip
+    assert np.allclose(dev.chi2, res.chi2, rtol=1e-6, atol=1e-6)
     # truncation biases the pixels by ~0.5 px; the pose must still land within a few mm / mrad
     d = res.pose @ np.linalg.inv(T_true)
     assert np.linalg.norm(d[:3, 3]) < 0.02 and np.arccos(np.clip((np.trace(d[:3, :3]) - 1) / 2, -1, 1)) < 3e-3
@@ -52,8 +57,25 @@ def test_pose_only_recovers_pose_and_rejects_outliers(gpu_ctx):
 def test_pose_only_degenerate_inputs(gpu_ctx):
     from backend import Backend
 
-    res = Backend().optimize_pose(np.eye(4), np.zeros((0, 3)), np.zeros((0, 2)), FX, FY, CX, CY)
-    assert res.n_inliers == 0 and np.array_equal(res.pose, np.eye(4))
+    for on_device in (False, True):
+        res = Backend().optimize_pose(np.eye(4), np.zeros((0, 3)), np.zeros((0, 2)), FX, FY, CX, CY, on_device=on_device)
+        assert res.n_inliers == 0 and np.array_equal(res.pose, np.eye(4))
+
+
+@pytest.mark.parametrize("O", [5, 64, 257, 3000])
+def test_device_and_host_lm_agree(gpu_ctx, O):
+    from backend import Backend
+    from slamhip.pose_opt import se3_exp
+
+    rng = np.random.default_rng(O)
+    T, X = _scene(rng, 1, O)
+    meas = _project(T[0], X) + rng.normal(0, 0.5, (O, 2))
+    meas[:: 7] += 60.0
+    T_init = se3_exp(rng.normal(0, 0.02, 6)) @ T[0]
+    a = Backend().optimize_pose(T_init, X, meas, FX, FY, CX, CY, on_device=False)
+    b = Backend().optimize_pose(T_init, X, meas, FX, FY, CX, CY, on_device=True)
+    assert np.allclose(a.pose, b.pose, rtol=0, atol=1e-7) and np.array_equal(a.inliers, b.inliers)
+    assert a.n_inliers == b.n_inliers
 
 
 def test_windowed_ba_reduces_cost_and_recovers_geometry(gpu_ctx):

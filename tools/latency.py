@@ -25,3 +25,19 @@ t0 = time.perf_counter()
 for f in fr[1:]:
     rm.push(f)
 print(f"ResidentMatcher.push n=200: {(time.perf_counter() - t0) / 59 * 1e3:.3f} ms per frame")
+
+# pose-only refinement: the reference's per-frame _correct_current_pose (<= 200 edges)
+from backend import Backend
+from slamhip.pose_opt import se3_exp
+be = Backend()
+X = np.c_[rng.uniform(-4, 4, (200, 2)), rng.uniform(6, 15, 200)]
+T = np.eye(4)
+pix = np.c_[458.654 * X[:, 0] / X[:, 2] + 367.215, 457.296 * X[:, 1] / X[:, 2] + 248.375] + rng.normal(0, 0.3, (200, 2))
+T0 = se3_exp([0.01, -0.01, 0.005, 0.05, -0.03, 0.04]) @ T
+for on_device in (False, True):
+    for _ in range(3):
+        be.optimize_pose(T0, X, pix, 458.654, 457.296, 367.215, 248.375, on_device=on_device)
+    t0 = time.perf_counter()
+    for _ in range(20):
+        r = be.optimize_pose(T0, X, pix, 458.654, 457.296, 367.215, 248.375, on_device=on_device)
+    print(f"optimize_pose 200 edges, {'one launch on device' if on_device else 'host-driven LM      '}: {(time.perf_counter() - t0) / 20 * 1e3:7.3f} ms per call, {r.iterations} accepted steps")
