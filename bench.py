@@ -44,6 +44,7 @@ VALU_LANES_PER_S = 256 * 4 * 32 * 2.4e9   # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz
 OPS_PER_PAIR = 16                 # 8 v_xor + 8 v_bcnt per 256-bit pair (algorithmic minimum, no MFMA)
 # measured issue cost (tools/ubench/valu_rate.hip): v_xor 2 cycles, v_bcnt 4 cycles per wave64
 CYCLES_PER_PAIRSTEP = 8 * 2 + 8 * 4
+ROW_LOOP_CYCLES = 54.8            # measured: isolated [lgkmcnt wait, 8 v_xor, 8 v_bcnt, 2 ds_read_b128] row loop, 2.38 GHz
 
 
 def profiled_traffic(kernel: str):
@@ -277,7 +278,10 @@ def main() -> int:
                 "valu_int": {"lane_ops_per_pair": OPS_PER_PAIR, "achieved_lane_ops_per_s": lane_ops,
                              "peak_lane_ops_per_s": VALU_LANES_PER_S, "frac_of_32lane_peak": lane_ops / VALU_LANES_PER_S,
                              "issue_floor_ms": cyc_floor_ms, "frac_of_issue_floor": cyc_floor_ms / kernel_ms,
-                             "issue_model": "v_xor 2 cyc + v_bcnt 4 cyc per wave64 (measured), 2.4 GHz"}},
+                             "issue_model": "v_xor 2 cyc + v_bcnt 4 cyc per wave64 (measured), 2.4 GHz",
+                             # tools/ubench/ring_probe.hip: the bare row loop (wait, 16 VALU, 2 ds_read_b128) at 8 waves/SIMD
+                             "isolated_row_loop_cycles": ROW_LOOP_CYCLES,
+                             "frac_of_isolated_row_loop": (local_pairs / 64 * ROW_LOOP_CYCLES / (256 * 4) / 2.38e9 * 1e3) / kernel_ms}},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(query, train)
