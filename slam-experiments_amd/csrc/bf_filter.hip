@@ -4,7 +4,7 @@
 // BASELINE.json names as extensions (the reference itself never uses them).
 #include "internal.h"
 
-struct filter_scratch {        // lives at the start of the ctx workspace tail
+struct filter_scratch {        // lives in the 4 KiB per-context device scratch (ctx->scratch)
     int min_dist;              // min 1-NN distance over all queries
     int pad;
     unsigned long long count;  // rows kept
