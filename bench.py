@@ -32,6 +32,7 @@ import numpy as np
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: required for multi-process RCCL on this pool
 if int(os.environ.get("WORLD_SIZE", "1")) > 1:
     os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")       # single node: bootstrap over loopback, no NIC needed
+    os.environ.setdefault("NCCL_IB_DISABLE", "1")           # ... and no InfiniBand probing; the data path is xGMI P2P
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (os.path.join(ROOT, "slam-experiments_amd"), ROOT):
     if p not in sys.path:
