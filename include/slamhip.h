@@ -111,8 +111,9 @@ SLAM_API int slam_bf_knn2_u256_host(slam_ctx* ctx, const uint8_t* h_query, int64
                            const uint8_t* h_train, int64_t M,
                            int32_t* h_idx, int32_t* h_dist);
 
-/* Tuning override for experiments: R = queries per lane (0 = heuristic; 1, 2,
- * 4 or 8), blocks_per_cu = grid size target (0 = default 4).  Process-wide. */
+/* Tuning override for experiments: R = queries per lane (0 = shipped choice, 1;
+ * or 1, 2, 4, 8), blocks_per_cu = grid size target (0 = shipped choice: 32, or
+ * 64 for query sets with fewer query blocks than CUs).  Process-wide. */
 SLAM_API int slam_bf_set_tuning(int R, int blocks_per_cu);
 
 /* Post-match selection on the device (feature_matchers.py:41-43 and the
