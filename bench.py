@@ -84,7 +84,7 @@ def cpu_baseline(query: np.ndarray, train: np.ndarray) -> dict:
         dt = min(dt, time.perf_counter() - t0)
     return {"value": rows * train.shape[0] / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
             "sample": f"{rows}x{train.shape[0]} (the same arrays), oracle/bf_hamming_oracle.c "
-                      f"(gcc -O3 -mpopcnt, OpenMP {cores} threads), best of 3 = {dt:.2f} s wall; cv2 is not installed on this host"}
+                      f"(gcc -O3, {oracle.bf_simd()}, OpenMP {cores} threads), best of 3 = {dt:.2f} s wall; cv2 is not installed on this host"}
 
 
 def reproj_bench(ctx, steps: int, warmup: int) -> dict:

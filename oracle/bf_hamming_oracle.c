@@ -45,19 +45,59 @@ static inline int hamming256(const uint8_t* a, const uint8_t* b) {
            __builtin_popcountll(x[2] ^ y[2]) + __builtin_popcountll(x[3] ^ y[3]);
 }
 
+/* batchDistHamming: distances of one query row to rows [0, n) of a train block, written to buf
+ * (OpenCV fills a per-row distance buffer the same way before the K-best pass).  Two builds of the
+ * same loop: portable, and AVX-512 VPOPCNTDQ where the host has it (gcc vectorises the popcounts);
+ * picked once at run time, so the .so built in the build container stays runnable on any x86-64 host. */
+static void dist_block_generic(const uint8_t* q, const uint8_t* t, int64_t n, int* buf) {
+    for (int64_t j = 0; j < n; j++) buf[j] = hamming256(q, t + j * DESC_BYTES);
+}
+
+__attribute__((target("avx512f,avx512vl,avx512vpopcntdq")))
+static void dist_block_avx512(const uint8_t* q, const uint8_t* t, int64_t n, int* buf) {
+    uint64_t x[4];
+    memcpy(x, q, 32);
+    for (int64_t j = 0; j < n; j++) {
+        uint64_t y[4];
+        memcpy(y, t + j * DESC_BYTES, 32);
+        buf[j] = __builtin_popcountll(x[0] ^ y[0]) + __builtin_popcountll(x[1] ^ y[1]) +
+                 __builtin_popcountll(x[2] ^ y[2]) + __builtin_popcountll(x[3] ^ y[3]);
+    }
+}
+
+static int have_avx512_popcnt(void) {
+    static int cached = -1;
+    if (cached < 0)
+        cached = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512vl") &&
+                 __builtin_cpu_supports("avx512vpopcntdq");
+    return cached;
+}
+
+/* which distance loop this host runs (reported by bench.py next to the CPU baseline) */
+const char* oracle_bf_simd(void) { return have_avx512_popcnt() ? "avx512-vpopcntdq" : "scalar-popcnt"; }
+
+#define DIST_BLOCK 2048
+
 /* BatchDistInvoker K-best insertion for one query row against rows
  * [0, M) of one train image; `update` is added to the stored index. */
 static void knn_insert_row(const uint8_t* q, const uint8_t* t, int64_t M, int K, int update, int* idx, int* dist) {
-    for (int64_t j = 0; j < M; j++) {
-        const int d = hamming256(q, t + j * DESC_BYTES);
-        if (d < dist[K - 1]) {
-            int k;
-            for (k = K - 2; k >= 0 && dist[k] > d; k--) {
-                idx[k + 1] = idx[k];
-                dist[k + 1] = dist[k];
+    int buf[DIST_BLOCK];
+    const int wide = have_avx512_popcnt();
+    for (int64_t j0 = 0; j0 < M; j0 += DIST_BLOCK) {
+        const int64_t n = M - j0 < DIST_BLOCK ? M - j0 : DIST_BLOCK;
+        if (wide) dist_block_avx512(q, t + j0 * DESC_BYTES, n, buf);
+        else dist_block_generic(q, t + j0 * DESC_BYTES, n, buf);
+        for (int64_t j = 0; j < n; j++) {
+            const int d = buf[j];
+            if (d < dist[K - 1]) {
+                int k;
+                for (k = K - 2; k >= 0 && dist[k] > d; k--) {
+                    idx[k + 1] = idx[k];
+                    dist[k + 1] = dist[k];
+                }
+                idx[k + 1] = (int)(j0 + j) + update;
+                dist[k + 1] = d;
             }
-            idx[k + 1] = (int)j + update;
-            dist[k + 1] = d;
         }
     }
 }

@@ -55,6 +55,8 @@ def _load():
         build()
     lib = ctypes.CDLL(_LIB_PATH)
     i64, i32, vp, dbl = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_double
+    lib.oracle_bf_simd.argtypes = []
+    lib.oracle_bf_simd.restype = ctypes.c_char_p
     lib.oracle_bf_knn_u256.argtypes = [vp, i64, vp, i64, i32, vp, vp, i32]
     lib.oracle_bf_knn_u256.restype = i32
     lib.oracle_bf_knn_multi_u256.argtypes = [vp, i64, vp, vp, i32, i32, vp, vp, i32]
@@ -82,6 +84,11 @@ def _desc(a: np.ndarray) -> np.ndarray:
 
 def _p(a: Optional[np.ndarray]):
     return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def bf_simd() -> str:
+    """Which distance loop liboracle runs on this host ("avx512-vpopcntdq" or "scalar-popcnt")."""
+    return _load().oracle_bf_simd().decode()
 
 
 # --------------------------------------------------------------------------
