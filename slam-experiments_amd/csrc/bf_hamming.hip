@@ -263,7 +263,12 @@ __global__ __launch_bounds__(256) void bf_top2_kernel(const uint4* __restrict__ 
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const int qi = qbase + r * 64;
-        if (qi < N) merge_into_slot(&st.best[qi], b1[r], b2[r]);
+        if (qi < N) {
+            // bound[q] >= the final 2nd-best distance: a block whose best row is already farther than that
+            // cannot contribute, so most chunk blocks skip the CAS (one 4-byte load instead)
+            const u32 g = __hip_atomic_load(&st.bound[qi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((b1[r] >> SLAM_KEY_IDX_BITS) <= g) merge_into_slot(&st.best[qi], b1[r], b2[r]);
+        }
     }
     // Arrival ticket (cdna_hip_programming.md G16, counter form): the merges above are returning
     // agent-scope atomics, already complete when the CAS loop exits; drain, barrier, one release,
