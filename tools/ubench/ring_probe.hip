@@ -21,7 +21,28 @@ __global__ __launch_bounds__(256) void k(const uint4* __restrict__ src, u32* out
     u32 base = (u32)(uintptr_t)(const __attribute__((address_space(3))) void*)tile;
     u32 addr = base; asm volatile("" : "+v"(addr));
     for (int it = 0; it < iters; it++) {
-        if (MODE == 0) {
+        if (MODE == 2) {
+            u32x4 r0a, r0c, r1a, r1c;
+            u32 a[16];
+            asm volatile("ds_read_b128 %0, %2 offset:0\n ds_read_b128 %1, %2 offset:16" : "=&v"(r0a), "=&v"(r0c) : "v"(addr));
+            asm volatile("ds_read_b128 %0, %2 offset:32\n ds_read_b128 %1, %2 offset:48" : "=&v"(r1a), "=&v"(r1c) : "v"(addr));
+#pragma unroll
+            for (int u = 0; u < 16; u += 2) {
+                a[u] = 0x80000000u - 60u; a[u + 1] = 0x80000000u - 60u;
+                asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+                ROW(a[u], r0a, r0c);
+                asm volatile("ds_read_b128 %0, %2 offset:%3\n ds_read_b128 %1, %2 offset:%4" : "=&v"(r0a), "=&v"(r0c) : "v"(addr), "n"(32 * (u + 2)), "n"(32 * (u + 2) + 16));
+                asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+                ROW(a[u + 1], r1a, r1c);
+                asm volatile("ds_read_b128 %0, %2 offset:%3\n ds_read_b128 %1, %2 offset:%4" : "=&v"(r1a), "=&v"(r1c) : "v"(addr), "n"(32 * (u + 3)), "n"(32 * (u + 3) + 16));
+            }
+            u32 m = a[0];
+#pragma unroll
+            for (int u = 1; u < 16; u++) m &= a[u];
+            if (__builtin_expect(__ballot((int)m >= 0) != 0ull, 0)) { acc0 += m; acc1 ^= a[3]; }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            asm volatile("" :: "v"(r0a), "v"(r0c), "v"(r1a), "v"(r1c));
+        } else if (MODE == 0) {
             u32x4 r0a, r0c, r1a, r1c;
             asm volatile("ds_read_b128 %0, %2 offset:0\n ds_read_b128 %1, %2 offset:16" : "=&v"(r0a), "=&v"(r0c) : "v"(addr));
             asm volatile("ds_read_b128 %0, %2 offset:32\n ds_read_b128 %1, %2 offset:48" : "=&v"(r1a), "=&v"(r1c) : "v"(addr));
@@ -62,7 +83,7 @@ __global__ __launch_bounds__(256) void k(const uint4* __restrict__ src, u32* out
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             asm volatile("" :: "v"(r0a), "v"(r0c), "v"(r1a), "v"(r1c));
         }
-        if (MODE == 0) { addr = base + (((it + 1) & 7) << 9); asm volatile("" : "+v"(addr)); }
+        if (MODE != 1) { addr = base + (((it + 1) & 7) << 9); asm volatile("" : "+v"(addr)); }
     }
     out[blockIdx.x * 256 + threadIdx.x] = acc0 + acc1;
 }
@@ -76,4 +97,4 @@ template <int MODE> int run(const uint4* src, u32* out, const char* name) {
     return 0;
 }
 int main() { uint4* src; u32* out; CK(hipMalloc(&src, 1024 * 16)); CK(hipMemset(src, 0x5A, 1024 * 16)); CK(hipMalloc(&out, 256 * 8 * 256 * 4));
-    run<0>(src, out, "warm"); run<0>(src, out, "lean: VGPR base + immediate offsets"); run<1>(src, out, "v_mov from SGPR per read + SALU"); run<0>(src, out, "lean again"); return 0; }
+    run<0>(src, out, "warm"); run<0>(src, out, "lean: VGPR base + immediate offsets"); run<1>(src, out, "v_mov from SGPR per read + SALU"); run<2>(src, out, "lean + 16-row AND filter, branch not taken"); run<0>(src, out, "lean again"); return 0; }
