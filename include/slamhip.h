@@ -178,6 +178,29 @@ SLAM_API int slam_pose_optimize_f64(slam_ctx* ctx, const double* d_pose_in, cons
                                     int rounds, int iterations, double chi2_threshold, double huber_delta,
                                     double* d_pose_out, uint8_t* d_inlier, double* d_chi2, int32_t* d_stats);
 
+/* Reduced camera system of a keyframe-window bundle adjustment (extension: the reference's Backend is an
+ * empty class, backend.py:101-103; residual/Jacobian arithmetic as frontend.py:272-291).  One call =
+ * linearise all O observations, Schur-eliminate the L points with damping `lambda`, and leave on device:
+ *   d_rec  [O,SLAM_BA_REC] per-observation blocks (Hpl, Y = Hpl E, ...), d_E [L,9] = (Hll+lambda I)^-1,
+ *   d_bl [L,3], d_Hpp [K,21] (upper triangles), d_bp [K,6], d_ybl [K,6] = sum Y bl, d_cost [K] (robust cost
+ *   per pose), d_W [K,K,36] with W[k1,k2] = sum_l Y_(k1,l) Hpl_(k2,l)^T for k1 <= k2 (other blocks untouched).
+ * The caller assembles S = blockdiag(Hpp + lambda I) - W (symmetric), rhs = -bp + ybl, solves for dp [K,6] and
+ * calls slam_ba_backsub_f64 for the point updates dl [L,3].
+ * Index tables (int32, device): obs_pose/obs_point [O]; pt_ptr [L+1]/pt_obs [O] = observations grouped by
+ * point; ps_ptr [K+1]/ps_obs [O] = grouped by pose; lookup [K,L] = observation index of (pose, point) or -1.
+ * All reductions run in a fixed order: results are bit-identical from run to run. */
+#define SLAM_BA_REC 73
+SLAM_API int slam_ba_reduce_f64(slam_ctx* ctx, const double* d_poses, int64_t K, const double* d_points,
+                                int64_t L, const int32_t* d_obs_pose, const int32_t* d_obs_point,
+                                const double* d_meas, int64_t O, const int32_t* d_pt_ptr, const int32_t* d_pt_obs,
+                                const int32_t* d_ps_ptr, const int32_t* d_ps_obs, const int32_t* d_lookup,
+                                double fx, double fy, double cx, double cy, double huber_delta, double lambda,
+                                double* d_rec, double* d_E, double* d_bl, double* d_Hpp, double* d_bp,
+                                double* d_ybl, double* d_cost, double* d_W);
+SLAM_API int slam_ba_backsub_f64(slam_ctx* ctx, int64_t L, const int32_t* d_pt_ptr, const int32_t* d_pt_obs,
+                                 const int32_t* d_obs_pose, const double* d_rec, const double* d_E,
+                                 const double* d_bl, const double* d_dp, double* d_dl);
+
 /* ---- multi-GPU: RCCL all-gather of per-shard result rows ---------------- */
 #define SLAM_COMM_ID_BYTES 128
 SLAM_API int slam_comm_unique_id(void* h_id /*[128]*/);

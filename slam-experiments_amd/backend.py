@@ -79,11 +79,14 @@ class Backend:
         return fn(pose, points, meas, (fx, fy, cx, cy), rounds, iterations, ctx=self.ctx)
 
     def optimize(self, poses, points, obs_pose_idx, obs_point_idx, meas, fx, fy, cx, cy, iterations: int = 10,
-                 fixed_poses=(0,), huber_delta: float = 0.0):
+                 fixed_poses=(0,), huber_delta: float = 0.0, on_device: bool = True):
         """Bundle adjustment over a window of keyframes and their landmarks (``optimizer.optimize(10)`` in
         spirit, ``frontend.py:362``; the reference's ``Backend`` has no body, ``backend.py:101-103``).
 
-        Residuals and both Jacobian blocks of every observation are built on the GPU each iteration; the
-        reduced camera system is assembled and solved on the host.  Returns ``slamhip.ba.BAResult``."""
-        return _ba.bundle_adjust(poses, points, obs_pose_idx, obs_point_idx, meas, (fx, fy, cx, cy), iterations,
-                                 fixed_poses, huber_delta, ctx=self.ctx)
+        With ``on_device`` (default) the linearisation, the elimination of the landmarks, the blocks of the
+        reduced camera system and the back-substitution run on the GPU (``slam_ba_reduce_f64`` /
+        ``slam_ba_backsub_f64``) and the host solves the 6K x 6K system; otherwise only residuals and
+        Jacobians come from the GPU and numpy does the rest.  Returns ``slamhip.ba.BAResult``."""
+        fn = _ba.bundle_adjust_device if on_device else _ba.bundle_adjust
+        return fn(poses, points, obs_pose_idx, obs_point_idx, meas, (fx, fy, cx, cy), iterations, fixed_poses,
+                  huber_delta, ctx=self.ctx)

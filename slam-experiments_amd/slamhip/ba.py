@@ -131,3 +131,155 @@ def bundle_adjust(poses, points, obs_pose_idx, obs_point_idx, meas, intrinsics, 
     finally:
         prob.free()
     return BAResult(poses=T, points=X, chi2_initial=cost0, chi2_final=cost, iterations=accepted)
+
+
+class SchurProblem:
+    """Device-resident window for ``slam_ba_reduce_f64`` / ``slam_ba_backsub_f64``: the observation list, its
+    two groupings (by point, by pose), the (pose, point) -> observation table and all output blocks."""
+
+    REC = 73   # SLAM_BA_REC
+
+    def __init__(self, ctx: Context, K: int, L: int, obs_pose, obs_point, meas, intrinsics):
+        from ._lib import check
+        self._check = check
+        self.ctx = ctx
+        op = np.ascontiguousarray(obs_pose, np.int32).reshape(-1)
+        ol = np.ascontiguousarray(obs_point, np.int32).reshape(-1)
+        meas = np.ascontiguousarray(meas, np.float64).reshape(-1, 2)
+        O = op.shape[0]
+        if ol.shape[0] != O or meas.shape[0] != O:
+            raise ValueError("obs_pose, obs_point and meas must have one row per observation")
+        if K < 1 or L < 1:
+            raise ValueError("need at least one pose and one point")
+        if O and (op.min() < 0 or op.max() >= K or ol.min() < 0 or ol.max() >= L):
+            raise ValueError("observation index out of range")
+        lookup = np.full((K, L), -1, np.int32)
+        lookup[op, ol] = np.arange(O, dtype=np.int32)
+        if int((lookup >= 0).sum()) != O:
+            raise ValueError("a (pose, point) pair is observed more than once")
+        self.K, self.L, self.O = K, L, O
+        self.fx, self.fy, self.cx, self.cy = (float(v) for v in intrinsics)
+        pt_obs = np.argsort(ol, kind="stable").astype(np.int32)
+        ps_obs = np.argsort(op, kind="stable").astype(np.int32)
+        pt_ptr = np.zeros(L + 1, np.int32); pt_ptr[1:] = np.cumsum(np.bincount(ol, minlength=L))
+        ps_ptr = np.zeros(K + 1, np.int32); ps_ptr[1:] = np.cumsum(np.bincount(op, minlength=K))
+        pad = lambda a: a if a.size else np.zeros(1, a.dtype)
+        up = ctx.upload
+        self.d_op, self.d_ol, self.d_meas = up(pad(op)), up(pad(ol)), up(meas if O else np.zeros((1, 2)))
+        self.d_pt_ptr, self.d_pt_obs, self.d_ps_ptr, self.d_ps_obs = up(pt_ptr), up(pad(pt_obs)), up(ps_ptr), up(pad(ps_obs))
+        self.d_lookup = up(lookup)
+        self.d_poses, self.d_points = ctx.malloc(K * 96), ctx.malloc(L * 24)
+        o = max(O, 1)
+        self.d_rec, self.d_E, self.d_bl = ctx.malloc(o * self.REC * 8), ctx.malloc(L * 72), ctx.malloc(L * 24)
+        self.d_Hpp, self.d_bp, self.d_ybl, self.d_cost = ctx.malloc(K * 168), ctx.malloc(K * 48), ctx.malloc(K * 48), ctx.malloc(K * 8)
+        self.d_W = ctx.malloc(K * K * 288)
+        self.d_dp, self.d_dl = ctx.malloc(K * 48), ctx.malloc(L * 24)
+        self._iu = np.triu_indices(6)
+
+    def reduce(self, poses12, points, huber_delta: float, lam: float):
+        """-> (S [K,K,6,6] symmetric, rhs [K,6], bp [K,6], cost) at this state and damping."""
+        c, K = self.ctx, self.K
+        self.d_poses.upload(np.ascontiguousarray(poses12, np.float64).reshape(K, 12))
+        self.d_points.upload(np.ascontiguousarray(points, np.float64).reshape(self.L, 3))
+        self._check(c.lib.slam_ba_reduce_f64(
+            c.handle, self.d_poses.ptr, K, self.d_points.ptr, self.L, self.d_op.ptr, self.d_ol.ptr, self.d_meas.ptr,
+            self.O, self.d_pt_ptr.ptr, self.d_pt_obs.ptr, self.d_ps_ptr.ptr, self.d_ps_obs.ptr, self.d_lookup.ptr,
+            self.fx, self.fy, self.cx, self.cy, float(huber_delta), float(lam), self.d_rec.ptr, self.d_E.ptr,
+            self.d_bl.ptr, self.d_Hpp.ptr, self.d_bp.ptr, self.d_ybl.ptr, self.d_cost.ptr, self.d_W.ptr))
+        tri = self.d_Hpp.download(np.float64, (K, 21))
+        bp = self.d_bp.download(np.float64, (K, 6))
+        ybl = self.d_ybl.download(np.float64, (K, 6))
+        cost = float(self.d_cost.download(np.float64, (K,)).sum())
+        W = self.d_W.download(np.float64, (K, K, 6, 6))
+        Hpp = np.zeros((K, 6, 6))
+        Hpp[:, self._iu[0], self._iu[1]] = tri
+        Hpp[:, self._iu[1], self._iu[0]] = tri
+        S = np.zeros((K, K, 6, 6))
+        for k1 in range(K):
+            S[k1, k1] = Hpp[k1] + lam * np.eye(6) - W[k1, k1]
+            for k2 in range(k1 + 1, K):
+                S[k1, k2] = -W[k1, k2]
+                S[k2, k1] = -W[k1, k2].T
+        return S, -bp + ybl, bp, cost
+
+    def cost(self, poses12, points, huber_delta: float) -> float:
+        return self.reduce(poses12, points, huber_delta, 1.0)[3]
+
+    def back_substitute(self, dp):
+        """dp [K,6] -> (dl [L,3], bl [L,3]) for the system of the last ``reduce``."""
+        c = self.ctx
+        self.d_dp.upload(np.ascontiguousarray(dp, np.float64).reshape(self.K, 6))
+        self._check(c.lib.slam_ba_backsub_f64(c.handle, self.L, self.d_pt_ptr.ptr, self.d_pt_obs.ptr, self.d_op.ptr,
+                                              self.d_rec.ptr, self.d_E.ptr, self.d_bl.ptr, self.d_dp.ptr, self.d_dl.ptr))
+        return self.d_dl.download(np.float64, (self.L, 3)), self.d_bl.download(np.float64, (self.L, 3))
+
+    def diag_max(self) -> float:
+        """Largest diagonal entry of Hpp / Hll of the last ``reduce`` (g2o-style initial damping)."""
+        tri = self.d_Hpp.download(np.float64, (self.K, 21))
+        d = tri[:, [0, 6, 11, 15, 18, 20]].max(initial=0.0)
+        if self.O:
+            rec = self.d_rec.download(np.float64, (self.O, self.REC))
+            hl = np.zeros((self.L, 3))
+            np.add.at(hl, self.d_ol.download(np.int32, (self.O,)), rec[:, [63, 66, 68]])
+            d = max(d, hl.max(initial=0.0))
+        return float(d)
+
+    def free(self) -> None:
+        for name, b in list(vars(self).items()):
+            if name.startswith("d_") and b is not None:
+                b.free()
+                setattr(self, name, None)
+
+
+def bundle_adjust_device(poses, points, obs_pose_idx, obs_point_idx, meas, intrinsics, iterations: int = 10,
+                         fixed_poses: Sequence[int] = (0,), huber_delta: float = 0.0,
+                         ctx: Optional[Context] = None) -> BAResult:
+    """``bundle_adjust`` with the linearisation, the point elimination, the reduced camera blocks and the
+    back-substitution on the GPU (``slam_ba_reduce_f64`` / ``slam_ba_backsub_f64``); the host only solves the
+    6K x 6K reduced system and drives the same LM schedule."""
+    ctx = ctx or default_context()
+    P = np.asarray(poses, np.float64)
+    T = np.tile(np.eye(4), (P.shape[0], 1, 1))
+    T[:, :3, :4] = (P.reshape(-1, 12) if P.ndim == 2 else poses_to_rt12(P)).reshape(-1, 3, 4)
+    X = np.array(points, np.float64).reshape(-1, 3)
+    K, L = T.shape[0], X.shape[0]
+    free = np.ones(K, bool)
+    free[list(fixed_poses)] = False
+    fidx = np.flatnonzero(free)
+    prob = SchurProblem(ctx, K, L, obs_pose_idx, obs_point_idx, meas, intrinsics)
+    rt = lambda Tc: Tc[:, :3, :4].reshape(K, 12)
+    try:
+        S, rhs, bp, cost = prob.reduce(rt(T), X, huber_delta, 1.0)
+        cost0 = cost
+        lam = 1e-5 * max(prob.diag_max(), 1e-12)
+        ni, accepted = 2.0, 0
+        for _ in range(iterations):
+            step_ok = False
+            for _trial in range(10):
+                S, rhs, bp, cost = prob.reduce(rt(T), X, huber_delta, lam)
+                Sf = S[np.ix_(fidx, fidx)].transpose(0, 2, 1, 3).reshape(6 * len(fidx), 6 * len(fidx))
+                try:
+                    dxp_f = np.linalg.solve(Sf, rhs[fidx].reshape(-1)).reshape(-1, 6)
+                except np.linalg.LinAlgError:
+                    lam *= ni; ni *= 2
+                    continue
+                dxp = np.zeros((K, 6)); dxp[fidx] = dxp_f
+                dxl, bl = prob.back_substitute(dxp)
+                Tn = np.stack([se3_exp(dxp[k]) @ T[k] for k in range(K)])
+                Xn = X + dxl
+                new = prob.cost(rt(Tn), Xn, huber_delta)
+                scale = float((dxp * (lam * dxp - bp)).sum() + (dxl * (lam * dxl - bl)).sum()) + 1e-3
+                rho = (cost - new) / scale
+                if rho > 0 and np.isfinite(new):
+                    T, X, cost = Tn, Xn, new
+                    lam *= max(1.0 / 3.0, min(1.0 - (2 * rho - 1) ** 3, 2.0 / 3.0))
+                    ni = 2.0
+                    accepted += 1
+                    step_ok = True
+                    break
+                lam *= ni; ni *= 2
+            if not step_ok:
+                break
+    finally:
+        prob.free()
+    return BAResult(poses=T, points=X, chi2_initial=cost0, chi2_final=cost, iterations=accepted)

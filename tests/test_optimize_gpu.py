@@ -98,3 +98,103 @@ def test_windowed_ba_reduces_cost_and_recovers_geometry(gpu_ctx):
     err = np.linalg.norm(res.points - X, axis=1)        # depth of weakly observed points stays noisy (short baselines)
     assert np.median(err) < 0.6 * np.median(np.linalg.norm(X0 - X, axis=1))
     assert np.array_equal(res.poses[0], T0[0]) and np.array_equal(res.poses[1], T0[1])   # gauge poses untouched
+
+
+def _window(rng, K, L, vis=0.7, noise=0.2):
+    T, X = _scene(rng, K, L)
+    op = np.repeat(np.arange(K), L).astype(np.int32)
+    ol = np.tile(np.arange(L), K).astype(np.int32)
+    keep = rng.uniform(size=K * L) < vis
+    op, ol = op[keep], ol[keep]
+    perm = rng.permutation(len(op))                     # observation order is arbitrary
+    op, ol = op[perm], ol[perm]
+    meas = np.stack([_project(T[k], X[l:l + 1])[0] for k, l in zip(op, ol)]) + rng.normal(0, noise, (len(op), 2))
+    return T, X, op, ol, meas
+
+
+@pytest.mark.parametrize("K,L,delta", [(7, 300, 0.0), (3, 40, 1.5), (16, 1000, 2.0), (1, 5, 0.0)])
+def test_reduced_camera_system_matches_host_schur(gpu_ctx, K, L, delta):
+    """slam_ba_reduce_f64 / slam_ba_backsub_f64 against the same algebra in numpy on the e/J the
+    residual kernel produces (f64; tolerance 1e-9 relative to the largest entry of each quantity)."""
+    from slamhip.ba import SchurProblem, _huber_weights, _robust_cost
+    from slamhip.reproj import ReprojProblem
+
+    rng = np.random.default_rng(1000 * K + L)
+    T, X, op, ol, meas = _window(rng, K, L, noise=1.0)
+    X = X.copy(); X[-1] += 0.0
+    if L > 5:                                           # one point nobody observes
+        sel = ol != L - 1
+        op, ol, meas = op[sel], ol[sel], meas[sel]
+    lam = 3.7
+    rp = ReprojProblem(gpu_ctx, T[:, :3, :4].reshape(K, 12), X, op, ol, meas, (FX, FY, CX, CY), with_point=True)
+    rp.linearize()
+    e, Jp, Jq = rp.download()
+    rp.free()
+    w = _huber_weights(e, delta)
+    O = len(op)
+    Hpp = np.zeros((K, 6, 6)); bp = np.zeros((K, 6)); Hll = np.zeros((L, 3, 3)); bl = np.zeros((L, 3))
+    np.add.at(Hpp, op, np.einsum("o,oia,oib->oab", w, Jp, Jp))
+    np.add.at(bp, op, np.einsum("o,oia,oi->oa", w, Jp, e))
+    np.add.at(Hll, ol, np.einsum("o,oia,oib->oab", w, Jq, Jq))
+    np.add.at(bl, ol, np.einsum("o,oia,oi->oa", w, Jq, e))
+    Hpl = np.einsum("o,oia,oib->oab", w, Jp, Jq)
+    seen = np.zeros(L, bool); seen[ol] = True
+    Hd = Hll + lam * np.eye(3); Hd[~seen] = np.eye(3)
+    Einv = np.linalg.inv(Hd)
+    Y = np.einsum("oab,obc->oac", Hpl, Einv[ol])
+    S = np.zeros((K, K, 6, 6))
+    for k in range(K):
+        S[k, k] = Hpp[k] + lam * np.eye(6)
+    for l in range(L):
+        obs = np.flatnonzero(ol == l)
+        if len(obs):
+            S[np.ix_(op[obs], op[obs])] -= np.einsum("iab,jcb->ijac", Y[obs], Hpl[obs])
+    rhs = -bp.copy()
+    np.add.at(rhs, op, np.einsum("oab,ob->oa", Y, bl[ol]))
+
+    sp = SchurProblem(gpu_ctx, K, L, op, ol, meas, (FX, FY, CX, CY))
+    try:
+        S_d, rhs_d, bp_d, cost_d = sp.reduce(T[:, :3, :4].reshape(K, 12), X, delta, lam)
+        S_d2, rhs_d2, _, cost_d2 = sp.reduce(T[:, :3, :4].reshape(K, 12), X, delta, lam)
+        assert np.array_equal(S_d, S_d2) and np.array_equal(rhs_d, rhs_d2) and cost_d == cost_d2   # fixed-order sums
+        tol = lambda ref: 1e-9 * max(np.abs(ref).max(), 1e-300)
+        assert np.abs(S_d - S).max() <= tol(S)
+        assert np.abs(rhs_d - rhs).max() <= tol(rhs) and np.abs(bp_d - bp).max() <= tol(bp)
+        assert abs(cost_d - _robust_cost(e, delta)) <= 1e-9 * max(_robust_cost(e, delta), 1.0)
+        dp = rng.normal(0, 1e-3, (K, 6))
+        dl_d, bl_d = sp.back_substitute(dp)
+        tmp = -bl.copy()
+        np.subtract.at(tmp, ol, np.einsum("oab,oa->ob", Hpl, dp[op]))
+        dl = np.einsum("lab,lb->la", Einv, tmp); dl[~seen] = 0
+        assert np.abs(bl_d - bl).max() <= tol(bl) and np.abs(dl_d - dl).max() <= tol(dl)
+        assert (dl_d[~seen] == 0).all()
+    finally:
+        sp.free()
+
+
+def test_device_ba_matches_host_ba(gpu_ctx):
+    from slamhip.ba import bundle_adjust, bundle_adjust_device
+    from slamhip.pose_opt import se3_exp
+
+    rng = np.random.default_rng(77)
+    K, L = 7, 300
+    T, X, op, ol, meas = _window(rng, K, L)
+    T0 = np.stack([T[0], T[1]] + [se3_exp(rng.normal(0, 0.01, 6)) @ T[k] for k in range(2, K)])
+    X0 = X + rng.normal(0, 0.05, X.shape)
+    for delta in (0.0, 1.0):
+        a = bundle_adjust(T0, X0, op, ol, meas, (FX, FY, CX, CY), iterations=10, fixed_poses=(0, 1), huber_delta=delta, ctx=gpu_ctx)
+        b = bundle_adjust_device(T0, X0, op, ol, meas, (FX, FY, CX, CY), iterations=10, fixed_poses=(0, 1), huber_delta=delta, ctx=gpu_ctx)
+        assert abs(a.chi2_initial - b.chi2_initial) <= 1e-9 * a.chi2_initial
+        assert b.iterations > 0 and b.chi2_final < 0.05 * b.chi2_initial, (delta, b.chi2_initial, b.chi2_final)
+        assert abs(a.chi2_final - b.chi2_final) <= 1e-6 * a.chi2_final      # same schedule, same optimum
+        assert np.allclose(a.poses, b.poses, rtol=0, atol=1e-6) and np.allclose(a.points, b.points, rtol=0, atol=1e-5)
+        assert np.array_equal(b.poses[0], T0[0]) and np.array_equal(b.poses[1], T0[1])
+
+
+def test_schur_problem_rejects_bad_input(gpu_ctx):
+    from slamhip.ba import SchurProblem
+
+    with pytest.raises(ValueError):
+        SchurProblem(gpu_ctx, 2, 3, [0, 0], [1, 1], np.zeros((2, 2)), (FX, FY, CX, CY))      # duplicate (pose, point)
+    with pytest.raises(ValueError):
+        SchurProblem(gpu_ctx, 2, 3, [0, 2], [1, 1], np.zeros((2, 2)), (FX, FY, CX, CY))      # pose index out of range
