@@ -82,7 +82,13 @@ def cpu_baseline(query: np.ndarray, train: np.ndarray) -> dict:
         t0 = time.perf_counter()
         oracle.bf_knn_c(q, train, 2, threads=cores)
         dt = min(dt, time.perf_counter() - t0)
+    one_rows = 4096                                  # 1 thread on a 1/16 slice of the query rows: a few seconds
+    t0 = time.perf_counter()
+    oracle.bf_knn_c(q[:one_rows], train, 2, threads=1)
+    dt1 = time.perf_counter() - t0
     return {"value": rows * train.shape[0] / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
+            "single_thread": {"value": one_rows * train.shape[0] / dt1, "unit": "pairs/s",
+                              "sample": f"first {one_rows} query rows x {train.shape[0]}, {dt1:.2f} s"},
             "sample": f"{rows}x{train.shape[0]} (the same arrays), oracle/bf_hamming_oracle.c "
                       f"(gcc -O3, {oracle.bf_simd()}, OpenMP {cores} threads), best of 3 = {dt:.2f} s wall; cv2 is not installed on this host"}
 
