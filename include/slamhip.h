@@ -178,6 +178,25 @@ SLAM_API int slam_pose_optimize_f64(slam_ctx* ctx, const double* d_pose_in, cons
                                     int rounds, int iterations, double chi2_threshold, double huber_delta,
                                     double* d_pose_out, uint8_t* d_inlier, double* d_chi2, int32_t* d_stats);
 
+/* ---- per-frame calls on caller-owned host buffers: one upload, one download, one synchronisation ---- */
+/* BruteForceFeatureMatcher.match (feature_matchers.py:36-44; cv2.BFMatcher.match + the min-distance filter) in
+ * one call.  Query rows h_query [N,32]; train rows either h_train [M,32] (host) or d_train (device, e.g. the
+ * previous frame kept by an earlier call) - exactly one of them when M > 0.  If d_query_keep is non-null the
+ * query rows are uploaded there (32*N bytes, caller-allocated with slam_malloc) so the next frame can pass it
+ * as d_train.  mode/param as slam_bf_match_filter.  Outputs (caller-allocated, N entries each): the kept
+ * matches in ascending query order as query index, train index and distance (float32, integer-valued like
+ * cv2's); *h_count = how many.  N == 0 or M == 0: no matches, not an error. */
+SLAM_API int slam_bf_match_host(slam_ctx* ctx, const uint8_t* h_query, int64_t N, const uint8_t* h_train,
+                                const void* d_train, int64_t M, void* d_query_keep, int mode, double param,
+                                int32_t* h_query_idx, int32_t* h_train_idx, float* h_distance, int64_t* h_count);
+/* slam_pose_optimize_f64 on host buffers (Frontend._correct_current_pose, frontend.py:298-393): h_pose_in [12],
+ * h_points [O,3], h_meas [O,2] -> h_pose_out [12], h_inlier uint8 [O], h_chi2 [O], h_stats int32 [2]. */
+SLAM_API int slam_pose_optimize_host_f64(slam_ctx* ctx, const double* h_pose_in, const double* h_points,
+                                         const double* h_meas, int64_t O, double fx, double fy, double cx,
+                                         double cy, int rounds, int iterations, double chi2_threshold,
+                                         double huber_delta, double* h_pose_out, uint8_t* h_inlier,
+                                         double* h_chi2, int32_t* h_stats);
+
 /* Reduced camera system of a keyframe-window bundle adjustment (extension: the reference's Backend is an
  * empty class, backend.py:101-103; residual/Jacobian arithmetic as frontend.py:272-291).  One call =
  * linearise all O observations, Schur-eliminate the L points with damping `lambda`, and leave on device:

@@ -58,8 +58,65 @@ __global__ __launch_bounds__(256) void filter_keep_kernel(const int2* __restrict
     if ((threadIdx.x & 63) == 0 && kept) atomicAdd(&s->count, (unsigned long long)kept);
 }
 
+// Both steps in one workgroup for frame-sized inputs: saves two launches on the path the reference runs per frame.
+#define FILTER_SMALL_MAX 16384
+__global__ __launch_bounds__(1024) void filter_small_kernel(const int2* __restrict__ idx, const int2* __restrict__ dist,
+                                                            int N, int mode, double param, filter_scratch* s,
+                                                            uint8_t* __restrict__ keep) {
+    __shared__ int s_min[16];
+    __shared__ unsigned int s_cnt[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int m = SLAM_NO_MATCH_DIST;
+    for (int n = threadIdx.x; n < N; n += 1024)
+        if (idx[n].x >= 0) m = min(m, dist[n].x);
+    m = wave_min_i32(m);
+    if (lane == 0) s_min[wave] = m;
+    __syncthreads();
+    int min_dist = SLAM_NO_MATCH_DIST;
+#pragma unroll
+    for (int w = 0; w < 16; w++) min_dist = min(min_dist, s_min[w]);
+    unsigned int kept = 0;
+    for (int n = threadIdx.x; n < N; n += 1024) {
+        const int2 i = idx[n], d = dist[n];
+        bool k = i.x >= 0;
+        if (mode == 1) k = k && (double)d.x < fmax(2.0 * (double)min_dist, param);       // feature_matchers.py:43
+        else if (mode == 2) k = k && i.y >= 0 && (double)d.x < param * (double)d.y;       // Lowe ratio
+        keep[n] = k ? 1 : 0;
+        kept += k ? 1u : 0u;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) kept += __shfl_xor(kept, off, 64);
+    if (lane == 0) s_cnt[wave] = kept;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long c = 0;
+        for (int w = 0; w < 16; w++) c += s_cnt[w];
+        s->min_dist = min_dist;
+        s->pad = 0;
+        s->count = c;
+    }
+}
+
 static int filter_scratch_ptr(slam_ctx* ctx, filter_scratch** out) {
     *out = (filter_scratch*)ctx->scratch;  // 4 KiB per-context device scratch, allocated at ctx creation
+    return SLAM_OK;
+}
+
+int slam_filter_launch(slam_ctx* ctx, const int32_t* d_idx, const int32_t* d_dist, int64_t N, int mode, double param,
+                       uint8_t* d_keep) {
+    filter_scratch* s = nullptr;
+    if (int rc = filter_scratch_ptr(ctx, &s)) return rc;
+    if (N <= FILTER_SMALL_MAX) {
+        filter_small_kernel<<<1, 1024, 0, ctx->stream>>>((const int2*)d_idx, (const int2*)d_dist, (int)N, mode, param,
+                                                         s, d_keep);
+    } else {
+        const int blocks = (int)((N + 255) / 256 < 2048 ? (N + 255) / 256 : 2048);
+        filter_init_kernel<<<1, 1, 0, ctx->stream>>>(s);
+        filter_min_kernel<<<blocks, 256, 0, ctx->stream>>>((const int2*)d_idx, (const int2*)d_dist, (int)N, s);
+        filter_keep_kernel<<<blocks, 256, 0, ctx->stream>>>((const int2*)d_idx, (const int2*)d_dist, (int)N, mode,
+                                                            param, s, d_keep);
+    }
+    SLAM_HIP(hipGetLastError());
     return SLAM_OK;
 }
 
@@ -74,16 +131,9 @@ extern "C" int slam_bf_match_filter(slam_ctx* ctx, const int32_t* d_idx, const i
     if (N == 0) return SLAM_OK;
     SLAM_REQUIRE(d_idx && d_dist && d_keep, "slam_bf_match_filter: null device pointer");
     SLAM_HIP(hipSetDevice(ctx->device));
-    filter_scratch* s = nullptr;
-    if (int rc = filter_scratch_ptr(ctx, &s)) return rc;
-    const int blocks = (int)((N + 255) / 256 < 2048 ? (N + 255) / 256 : 2048);
-    filter_init_kernel<<<1, 1, 0, ctx->stream>>>(s);
-    filter_min_kernel<<<blocks, 256, 0, ctx->stream>>>((const int2*)d_idx, (const int2*)d_dist, (int)N, s);
-    filter_keep_kernel<<<blocks, 256, 0, ctx->stream>>>((const int2*)d_idx, (const int2*)d_dist, (int)N, mode,
-                                                        param, s, d_keep);
-    SLAM_HIP(hipGetLastError());
+    if (int rc = slam_filter_launch(ctx, d_idx, d_dist, N, mode, param, d_keep)) return rc;
     filter_scratch h;
-    SLAM_HIP(hipMemcpyAsync(&h, s, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    SLAM_HIP(hipMemcpyAsync(&h, ctx->scratch, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
     SLAM_HIP(hipStreamSynchronize(ctx->stream));
     if (h_count) *h_count = (int64_t)h.count;
     if (h_min_dist) *h_min_dist = h.min_dist;

@@ -487,30 +487,3 @@ extern "C" int slam_bf_merge_top2(slam_ctx* ctx, const int32_t* d_idx_parts, con
     SLAM_HIP(hipGetLastError());
     return SLAM_OK;
 }
-
-extern "C" int slam_bf_knn2_u256_host(slam_ctx* ctx, const uint8_t* h_query, int64_t N, const uint8_t* h_train,
-                                      int64_t M, int32_t* h_idx, int32_t* h_dist) {
-    SLAM_REQUIRE(ctx, "slam_bf_knn2_u256_host: null ctx");
-    SLAM_REQUIRE(N >= 0 && M >= 0, "negative size");
-    if (N == 0) return SLAM_OK;
-    SLAM_REQUIRE(h_query && h_idx && h_dist && (h_train || M == 0), "slam_bf_knn2_u256_host: null host pointer");
-    void *dq = nullptr, *dt = nullptr, *di = nullptr, *dd = nullptr;
-    int rc = slam_malloc(ctx, (uint64_t)N * SLAM_DESC_BYTES, &dq);
-    if (!rc) rc = slam_malloc(ctx, (uint64_t)M * SLAM_DESC_BYTES, &dt);
-    if (!rc) rc = slam_malloc(ctx, (uint64_t)N * 8, &di);
-    if (!rc) rc = slam_malloc(ctx, (uint64_t)N * 8, &dd);
-    if (!rc) rc = slam_upload(ctx, dq, h_query, (uint64_t)N * SLAM_DESC_BYTES);
-    if (!rc && M) rc = slam_upload(ctx, dt, h_train, (uint64_t)M * SLAM_DESC_BYTES);
-    if (!rc) rc = slam_bf_knn2_u256(ctx, dq, N, dt, M, 0, (int32_t*)di, (int32_t*)dd);
-    if (!rc) rc = slam_download(ctx, h_idx, di, (uint64_t)N * 8);
-    if (!rc) rc = slam_download(ctx, h_dist, dd, (uint64_t)N * 8);
-    // keep the first error message: frees below must not overwrite it on failure
-    char saved[512];
-    if (rc) snprintf(saved, sizeof(saved), "%s", slam_last_error());
-    if (dq) slam_free(ctx, dq);
-    if (dt) slam_free(ctx, dt);
-    if (di) slam_free(ctx, di);
-    if (dd) slam_free(ctx, dd);
-    if (rc) slam_set_error(rc, "%s", saved);
-    return rc;
-}

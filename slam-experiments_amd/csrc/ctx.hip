@@ -68,6 +68,8 @@ extern "C" int slam_ctx_destroy(slam_ctx* ctx) {
     for (auto& kv : ctx->allocs) (void)hipFree(kv.first);
     if (ctx->workspace) (void)hipFree(ctx->workspace);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->io_dev) (void)hipFree(ctx->io_dev);
+    if (ctx->io_host) (void)hipHostFree(ctx->io_host);
     if (ctx->bf_state_mem) (void)hipFree(ctx->bf_state_mem);
     if (ctx->prof_ev) {
         for (int i = 0; i < 2 * slam_ctx::PROF_MAX; i++) (void)hipEventDestroy(ctx->prof_ev[i]);
@@ -159,6 +161,30 @@ int slam_workspace(slam_ctx* ctx, uint64_t bytes, void** out) {
         ctx->workspace_bytes = want;
     }
     *out = ctx->workspace;
+    return SLAM_OK;
+}
+
+int slam_io_arena(slam_ctx* ctx, uint64_t dev_bytes, uint64_t host_bytes, void** dev, void** host) {
+    std::lock_guard<std::mutex> g(ctx->mu);
+    if (dev_bytes > ctx->io_dev_bytes || host_bytes > ctx->io_host_bytes) SLAM_HIP(hipStreamSynchronize(ctx->stream));
+    if (dev_bytes > ctx->io_dev_bytes) {
+        if (ctx->io_dev) SLAM_HIP(hipFree(ctx->io_dev));
+        ctx->io_dev = nullptr;
+        ctx->io_dev_bytes = 0;
+        const uint64_t want = dev_bytes + (dev_bytes >> 2) + 4096;
+        SLAM_HIP(hipMalloc(&ctx->io_dev, want));
+        ctx->io_dev_bytes = want;
+    }
+    if (host_bytes > ctx->io_host_bytes) {
+        if (ctx->io_host) SLAM_HIP(hipHostFree(ctx->io_host));
+        ctx->io_host = nullptr;
+        ctx->io_host_bytes = 0;
+        const uint64_t want = host_bytes + (host_bytes >> 2) + 4096;
+        SLAM_HIP(hipHostMalloc(&ctx->io_host, want, hipHostMallocDefault));
+        ctx->io_host_bytes = want;
+    }
+    *dev = ctx->io_dev;
+    *host = ctx->io_host;
     return SLAM_OK;
 }
 

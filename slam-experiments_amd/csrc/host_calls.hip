@@ -1,0 +1,142 @@
+// host_calls.hip — the per-frame calls of the reference on caller-owned HOST buffers, one entry point each.
+//
+// At the reference's own sizes (<= 200 features per frame, slam.py:23) the kernels take tens of
+// microseconds and what a call costs is the number of PCIe round trips and synchronisations around them.
+// Each function here packs its inputs into one pinned staging block, does ONE host-to-device copy,
+// launches everything on the context stream, does ONE device-to-host copy and synchronises once.
+//   slam_bf_knn2_u256_host       cv2.BFMatcher.knnMatch(k=2) (the search behind feature_matchers.py:39)
+//   slam_bf_match_host           BruteForceFeatureMatcher.match (feature_matchers.py:36-44)
+//   slam_pose_optimize_host_f64  Frontend._correct_current_pose (frontend.py:298-393)
+#include "internal.h"
+#include <string.h>
+
+static inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
+
+extern "C" int slam_bf_knn2_u256_host(slam_ctx* ctx, const uint8_t* h_query, int64_t N, const uint8_t* h_train,
+                                      int64_t M, int32_t* h_idx, int32_t* h_dist) {
+    SLAM_REQUIRE(ctx, "slam_bf_knn2_u256_host: null ctx");
+    SLAM_REQUIRE(N >= 0 && M >= 0 && N <= (1ll << 28) && M <= (1ll << 28), "bad sizes N=%lld M=%lld", (long long)N, (long long)M);
+    if (N == 0) return SLAM_OK;
+    SLAM_REQUIRE(h_query && h_idx && h_dist && (h_train || M == 0), "slam_bf_knn2_u256_host: null host pointer");
+    SLAM_HIP(hipSetDevice(ctx->device));
+    const uint64_t qbytes = (uint64_t)N * SLAM_DESC_BYTES, tbytes = (uint64_t)M * SLAM_DESC_BYTES;
+    const uint64_t off_t = align_up(qbytes, 256), off_i = off_t + align_up(tbytes, 256);
+    const uint64_t off_d = off_i + (uint64_t)N * 8, total = align_up(off_d + (uint64_t)N * 8, 256);
+    void *dev = nullptr, *host = nullptr;
+    if (int rc = slam_io_arena(ctx, total, total, &dev, &host)) return rc;
+    uint8_t* hb = (uint8_t*)host;
+    uint8_t* db = (uint8_t*)dev;
+    memcpy(hb, h_query, qbytes);
+    if (tbytes) memcpy(hb + off_t, h_train, tbytes);
+    SLAM_HIP(hipMemcpyAsync(db, hb, off_t + tbytes, hipMemcpyHostToDevice, ctx->stream));
+    if (int rc = slam_bf_knn2_u256(ctx, db, N, db + off_t, M, 0, (int32_t*)(db + off_i), (int32_t*)(db + off_d))) return rc;
+    SLAM_HIP(hipMemcpyAsync(hb + off_i, db + off_i, (uint64_t)N * 16, hipMemcpyDeviceToHost, ctx->stream));
+    SLAM_HIP(hipStreamSynchronize(ctx->stream));
+    memcpy(h_idx, hb + off_i, (uint64_t)N * 8);
+    memcpy(h_dist, hb + off_d, (uint64_t)N * 8);
+    return SLAM_OK;
+}
+
+extern "C" int slam_bf_match_host(slam_ctx* ctx, const uint8_t* h_query, int64_t N, const uint8_t* h_train,
+                                  const void* d_train, int64_t M, void* d_query_keep, int mode, double param,
+                                  int32_t* h_query_idx, int32_t* h_train_idx, float* h_distance, int64_t* h_count) {
+    SLAM_REQUIRE(ctx, "slam_bf_match_host: null ctx");
+    SLAM_REQUIRE(h_count, "slam_bf_match_host: null h_count");
+    *h_count = 0;
+    SLAM_REQUIRE(N >= 0 && M >= 0 && N <= (1ll << 28) && M <= (1ll << 28), "bad sizes N=%lld M=%lld", (long long)N, (long long)M);
+    SLAM_REQUIRE(mode >= 0 && mode <= 2, "mode %d not in {0,1,2}", mode);
+    SLAM_REQUIRE(!(h_train && d_train), "pass the train descriptors either as h_train or as d_train, not both");
+    SLAM_REQUIRE(N == 0 || h_query, "slam_bf_match_host: null h_query");
+    SLAM_REQUIRE(N == 0 || (h_query_idx && h_train_idx && h_distance), "slam_bf_match_host: null output pointer");
+    SLAM_REQUIRE(M == 0 || h_train || d_train, "slam_bf_match_host: no train descriptors");
+    SLAM_HIP(hipSetDevice(ctx->device));
+    const uint64_t qbytes = (uint64_t)N * SLAM_DESC_BYTES, tbytes = h_train ? (uint64_t)M * SLAM_DESC_BYTES : 0;
+    if (N == 0 || M == 0) {
+        // nothing to report (OpenCV: no candidate -> no match); still hand the query rows over if asked to
+        if (N && d_query_keep) {
+            SLAM_HIP(hipMemcpyAsync(d_query_keep, h_query, qbytes, hipMemcpyHostToDevice, ctx->stream));
+            SLAM_HIP(hipStreamSynchronize(ctx->stream));
+        }
+        return SLAM_OK;
+    }
+    // device arena: [query | train | idx int32[N,2] | dist int32[N,2] | keep u8[N]]; staging mirrors it
+    const uint64_t off_t = align_up(qbytes, 256), off_i = off_t + align_up(tbytes, 256);
+    const uint64_t off_d = off_i + (uint64_t)N * 8, off_k = off_d + (uint64_t)N * 8, total = align_up(off_k + N, 256);
+    void *dev = nullptr, *host = nullptr;
+    if (int rc = slam_io_arena(ctx, total, total, &dev, &host)) return rc;
+    uint8_t* hb = (uint8_t*)host;
+    uint8_t* db = (uint8_t*)dev;
+    memcpy(hb, h_query, qbytes);
+    if (tbytes) memcpy(hb + off_t, h_train, tbytes);
+    const void* dq = db;
+    if (d_query_keep) {
+        // the caller keeps this frame's rows on the device as the next call's train side
+        SLAM_HIP(hipMemcpyAsync(d_query_keep, hb, qbytes, hipMemcpyHostToDevice, ctx->stream));
+        if (tbytes) SLAM_HIP(hipMemcpyAsync(db + off_t, hb + off_t, tbytes, hipMemcpyHostToDevice, ctx->stream));
+        dq = d_query_keep;
+    } else {
+        SLAM_HIP(hipMemcpyAsync(db, hb, off_t + tbytes, hipMemcpyHostToDevice, ctx->stream));
+    }
+    const void* dt = h_train ? (const void*)(db + off_t) : d_train;
+    int32_t* d_idx = (int32_t*)(db + off_i);
+    int32_t* d_dist = (int32_t*)(db + off_d);
+    if (int rc = slam_bf_knn2_u256(ctx, dq, N, dt, M, 0, d_idx, d_dist)) return rc;
+    if (int rc = slam_filter_launch(ctx, d_idx, d_dist, N, mode, param, db + off_k)) return rc;
+    SLAM_HIP(hipMemcpyAsync(hb + off_i, db + off_i, (uint64_t)N * 17, hipMemcpyDeviceToHost, ctx->stream));
+    SLAM_HIP(hipStreamSynchronize(ctx->stream));
+    // compact the kept rows (the selection itself was made on the device)
+    const int32_t* ri = (const int32_t*)(hb + off_i);
+    const int32_t* rd = (const int32_t*)(hb + off_d);
+    const uint8_t* rk = hb + off_k;
+    int64_t c = 0;
+    for (int64_t n = 0; n < N; n++) {
+        if (!rk[n]) continue;
+        h_query_idx[c] = (int32_t)n;
+        h_train_idx[c] = ri[2 * n];
+        h_distance[c] = (float)rd[2 * n];   // cv2 reports CV_32S distances converted to float32
+        c++;
+    }
+    *h_count = c;
+    return SLAM_OK;
+}
+
+extern "C" int slam_pose_optimize_host_f64(slam_ctx* ctx, const double* h_pose_in, const double* h_points,
+                                           const double* h_meas, int64_t O, double fx, double fy, double cx,
+                                           double cy, int rounds, int iterations, double chi2_threshold,
+                                           double huber_delta, double* h_pose_out, uint8_t* h_inlier,
+                                           double* h_chi2, int32_t* h_stats) {
+    SLAM_REQUIRE(ctx, "slam_pose_optimize_host_f64: null ctx");
+    SLAM_REQUIRE(O >= 0 && O <= (1 << 24), "O=%lld out of range [0, 2^24]", (long long)O);
+    SLAM_REQUIRE(h_pose_in && h_pose_out && h_stats && (O == 0 || (h_points && h_meas && h_inlier && h_chi2)),
+                 "slam_pose_optimize_host_f64: null host pointer");
+    SLAM_HIP(hipSetDevice(ctx->device));
+    // in: [pose 12 | points 3O | pad | meas 2O]   out: [pose 12 | chi2 O | stats (2 x int32) | inlier u8[O]]
+    const uint64_t o = (uint64_t)O;
+    const uint64_t off_p = 96, off_m = align_up(off_p + 24 * o, 16), in_bytes = align_up(off_m + 16 * o, 256);
+    const uint64_t out_pose = in_bytes, out_chi2 = out_pose + 96, out_stats = out_chi2 + 8 * o, out_inl = out_stats + 8;
+    const uint64_t total = align_up(out_inl + o + 1, 256);
+    void *dev = nullptr, *host = nullptr;
+    if (int rc = slam_io_arena(ctx, total, total, &dev, &host)) return rc;
+    uint8_t* hb = (uint8_t*)host;
+    uint8_t* db = (uint8_t*)dev;
+    memcpy(hb, h_pose_in, 96);
+    if (O) {
+        memcpy(hb + off_p, h_points, 24 * o);
+        memcpy(hb + off_m, h_meas, 16 * o);
+    }
+    SLAM_HIP(hipMemcpyAsync(db, hb, off_m + 16 * o, hipMemcpyHostToDevice, ctx->stream));
+    if (int rc = slam_pose_optimize_f64(ctx, (const double*)db, (const double*)(db + off_p), (const double*)(db + off_m),
+                                        O, fx, fy, cx, cy, rounds, iterations, chi2_threshold, huber_delta,
+                                        (double*)(db + out_pose), db + out_inl, (double*)(db + out_chi2),
+                                        (int32_t*)(db + out_stats)))
+        return rc;
+    SLAM_HIP(hipMemcpyAsync(hb + out_pose, db + out_pose, out_inl + o - out_pose, hipMemcpyDeviceToHost, ctx->stream));
+    SLAM_HIP(hipStreamSynchronize(ctx->stream));
+    memcpy(h_pose_out, hb + out_pose, 96);
+    memcpy(h_stats, hb + out_stats, 8);
+    if (O) {
+        memcpy(h_chi2, hb + out_chi2, 8 * o);
+        memcpy(h_inlier, hb + out_inl, o);
+    }
+    return SLAM_OK;
+}

@@ -19,6 +19,10 @@ struct slam_ctx {
     void* bf_state_mem = nullptr;                   // matcher merge state (best/bound/arrivals), clean between launches
     int64_t bf_state_rows = 0;
     void* scratch = nullptr;                        // 4 KiB device scratch (filter counters, reductions)
+    void* io_dev = nullptr;                         // device arena of the host-buffer entry points (grow-only)
+    uint64_t io_dev_bytes = 0;
+    void* io_host = nullptr;                        // pinned host staging for the same (grow-only)
+    uint64_t io_host_bytes = 0;
     // profiling of the dominant kernel
     int prof_on = 0;
     static const int PROF_MAX = 4096;
@@ -50,6 +54,11 @@ int slam_set_error(int code, const char* fmt, ...);
 
 // grows ctx->workspace to at least `bytes` (stream-synchronising when it grows)
 int slam_workspace(slam_ctx* ctx, uint64_t bytes, void** out);
+// device arena + pinned staging of at least these sizes for one host-buffer call (stream-synchronising when they grow)
+int slam_io_arena(slam_ctx* ctx, uint64_t dev_bytes, uint64_t host_bytes, void** dev, void** host);
+// the filter kernels of slam_bf_match_filter without the read-back (asynchronous on the ctx stream)
+int slam_filter_launch(slam_ctx* ctx, const int32_t* d_idx, const int32_t* d_dist, int64_t N, int mode, double param,
+                       uint8_t* d_keep);
 // event bracket around the dominant kernel when profiling is on
 int slam_prof_begin(slam_ctx* ctx);
 int slam_prof_end(slam_ctx* ctx);

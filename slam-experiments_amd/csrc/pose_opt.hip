@@ -7,9 +7,9 @@
 // Python callback from g2o's C++ (frontend.py:272-291), <= 200 edges x <= 40
 // iterations x 2 callbacks.  Here one 256-thread workgroup keeps the problem
 // on chip: every evaluation is a block-wide pass over the observations
-// (residual, 2x6 Jacobian, Huber weight, 27 sums by wave shuffle + fixed-order
-// cross-wave add, so results are run-to-run identical), lane 0 solves the damped
-// 6x6 system by Cholesky and drives g2o's published LM schedule.
+// (residual, 2x6 Jacobian, Huber weight, 28 sums through LDS in a fixed order,
+// so results are run-to-run identical), lane 0 solves the damped 6x6 system by
+// LDL^T and drives g2o's published LM schedule.
 //
 // Same structure and constants as slamhip/pose_opt.py (the host-driven version
 // the tests compare against): every round restarts from the input pose
@@ -23,6 +23,7 @@
 
 #define PO_THREADS 256
 #define PO_TERMS 28   // 21 (upper H) + 6 (b) + 1 (robust chi2 of the active edges)
+#define PO_STAGE 512  // observations kept in LDS (3 + 2 + 1 doubles and a flag each: 24.5 KiB)
 
 struct po_cam { double fx, fy, cx, cy; };
 
@@ -31,19 +32,17 @@ struct po_params {
     double chi2_threshold, huber_delta;
 };
 
-__device__ __forceinline__ double po_wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
-
 // exp([w, v]) * T for a 3x4 row-major pose (rotation first, g2o SE3Quat::exp ordering)
 __device__ void po_apply_update(const double* dx, const double* T, double* Tn) {
     const double wx = dx[0], wy = dx[1], wz = dx[2];
     const double th2 = wx * wx + wy * wy + wz * wz, th = sqrt(th2);
     double a, b, c;  // sin(th)/th, (1-cos)/th^2, (th-sin)/th^3
     if (th < 1e-10) { a = 1.0; b = 0.5; c = 1.0 / 6.0; }
-    else { a = sin(th) / th; b = (1.0 - cos(th)) / th2; c = (th - sin(th)) / (th2 * th); }
+    else {
+        double sn, cs;
+        sincos(th, &sn, &cs);
+        a = sn / th; b = (1.0 - cs) / th2; c = (th - sn) / (th2 * th);
+    }
     const double W[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
     double W2[9];
     for (int i = 0; i < 3; i++)
@@ -63,46 +62,59 @@ __device__ void po_apply_update(const double* dx, const double* T, double* Tn) {
     }
 }
 
-// solve (H + lam I) x = -b by Cholesky; H given as packed upper triangle s[0..20]; returns false if not SPD
+// solve (H + lam I) x = -b by LDL^T (six reciprocals, no square roots: this runs on one lane, so the length of
+// the dependent f64 chain is what it costs); H given as packed upper triangle s[0..20]; false if not SPD
 __device__ bool po_solve(const double* s, const double* b, double lam, double* x) {
     double A[36];
     int t = 0;
+#pragma unroll
     for (int i = 0; i < 6; i++)
+#pragma unroll
         for (int j = i; j < 6; j++) { A[i * 6 + j] = A[j * 6 + i] = s[t++]; }
+#pragma unroll
     for (int i = 0; i < 6; i++) A[i * 6 + i] += lam;
-    double L[36];
-    for (int i = 0; i < 36; i++) L[i] = 0.0;
+    double L[36], d[6], dinv[6];
+    bool spd = true;
+#pragma unroll
     for (int j = 0; j < 6; j++) {
-        double d = A[j * 6 + j];
-        for (int k = 0; k < j; k++) d -= L[j * 6 + k] * L[j * 6 + k];
-        if (!(d > 0.0) || !isfinite(d)) return false;
-        const double ljj = sqrt(d);
-        L[j * 6 + j] = ljj;
+        double v = A[j * 6 + j];
+#pragma unroll
+        for (int k = 0; k < j; k++) v -= L[j * 6 + k] * L[j * 6 + k] * d[k];
+        spd = spd && (v > 0.0) && isfinite(v);
+        d[j] = v;
+        dinv[j] = 1.0 / v;
+#pragma unroll
         for (int i = j + 1; i < 6; i++) {
-            double v = A[i * 6 + j];
-            for (int k = 0; k < j; k++) v -= L[i * 6 + k] * L[j * 6 + k];
-            L[i * 6 + j] = v / ljj;
+            double u = A[i * 6 + j];
+#pragma unroll
+            for (int k = 0; k < j; k++) u -= L[i * 6 + k] * L[j * 6 + k] * d[k];
+            L[i * 6 + j] = u * dinv[j];
         }
     }
+    if (!spd) return false;
     double y[6];
+#pragma unroll
     for (int i = 0; i < 6; i++) {
         double v = -b[i];
+#pragma unroll
         for (int k = 0; k < i; k++) v -= L[i * 6 + k] * y[k];
-        y[i] = v / L[i * 6 + i];
+        y[i] = v;
     }
+#pragma unroll
     for (int i = 5; i >= 0; i--) {
-        double v = y[i];
+        double v = y[i] * dinv[i];
+#pragma unroll
         for (int k = i + 1; k < 6; k++) v -= L[k * 6 + i] * x[k];
-        x[i] = v / L[i * 6 + i];
+        x[i] = v;
     }
     return true;
 }
 
 // One block-wide evaluation at pose T: sums[0..20] = upper H, [21..26] = b, [27] = robust chi2 over the
 // active edges; chi2[o] = e.e for every edge.  Every thread returns with the sums in `out` (shared).
-__device__ void po_evaluate(const double* T, const double* __restrict__ points, const double2* __restrict__ meas,
-                            const uint8_t* __restrict__ active, int O, po_cam cam, double delta,
-                            double* __restrict__ chi2, double (*sw)[PO_TERMS], double* out) {
+// points / meas / active / chi2 are generic pointers: the LDS copies when the problem is staged, else global.
+__device__ void po_evaluate(const double* T, const double* points, const double2* meas, const uint8_t* active, int O,
+                            po_cam cam, double delta, double* chi2, double* red, double* part, double* out) {
     double acc[PO_TERMS];
 #pragma unroll
     for (int i = 0; i < PO_TERMS; i++) acc[i] = 0.0;
@@ -136,52 +148,80 @@ __device__ void po_evaluate(const double* T, const double* __restrict__ points, 
         for (int a = 0; a < 6; a++) acc[21 + a] += w * (j0[a] * e0 + j1[a] * e1);
         acc[27] += rho;
     }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    __syncthreads();   // previous consumers of sw / out are done
+    // 28 sums over 256 threads through LDS, in two batches of 14 (28 KiB): thread (term, segment) adds its 32
+    // values in a rotated but fixed order (bank-conflict free, run-to-run identical), then 8 partials per term.
+    // Cross-lane shuffles cost ~170 dependent LDS round trips here; this is 2 x (14 writes + 32 reads) per thread.
+    const int tid = threadIdx.x;
 #pragma unroll
-    for (int i = 0; i < PO_TERMS; i++) {
-        const double s = po_wave_sum(acc[i]);
-        if (lane == 0) sw[wave][i] = s;
+    for (int half = 0; half < 2; half++) {
+        __syncthreads();   // previous readers of red / part / out are done
+#pragma unroll
+        for (int i = 0; i < PO_TERMS / 2; i++) red[i * PO_THREADS + tid] = acc[half * (PO_TERMS / 2) + i];
+        __syncthreads();
+        if (tid < (PO_TERMS / 2) * 8) {
+            const double* r = red + (tid >> 3) * PO_THREADS + (tid & 7) * 32;
+            double sum = 0.0;
+#pragma unroll
+            for (int k = 0; k < 32; k++) sum += r[(k + tid) & 31];
+            part[half * (PO_TERMS / 2) * 8 + tid] = sum;
+        }
     }
     __syncthreads();
-    if (threadIdx.x < PO_TERMS)
-        out[threadIdx.x] = ((sw[0][threadIdx.x] + sw[1][threadIdx.x]) + sw[2][threadIdx.x]) + sw[3][threadIdx.x];
+    if (tid < PO_TERMS) {
+        const double* q = part + tid * 8;
+        out[tid] = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
+    }
     __syncthreads();
 }
 
 __global__ __launch_bounds__(PO_THREADS) void pose_opt_kernel(const double* __restrict__ pose_in,
-                                                              const double* __restrict__ points,
-                                                              const double2* __restrict__ meas, int O, po_cam cam,
+                                                              const double* __restrict__ g_points,
+                                                              const double2* __restrict__ g_meas, int O, po_cam cam,
                                                               po_params prm, double* __restrict__ pose_out,
-                                                              uint8_t* __restrict__ active,
-                                                              double* __restrict__ chi2, int* __restrict__ stats) {
-    __shared__ double sw[4][PO_TERMS];
+                                                              uint8_t* __restrict__ g_active,
+                                                              double* __restrict__ g_chi2, int* __restrict__ stats) {
+    // A frame has <= 200 edges (slam.py:23): the whole problem lives in LDS (24.5 KiB) and no evaluation touches
+    // global memory.  Larger problems run the same code on the global arrays.
+    __shared__ double s_points[PO_STAGE * 3];
+    __shared__ double2 s_meas[PO_STAGE];
+    __shared__ double s_chi2[PO_STAGE];
+    __shared__ uint8_t s_active[PO_STAGE];
+    __shared__ double red[(PO_TERMS / 2) * PO_THREADS];
+    __shared__ double part[PO_TERMS * 8];
     __shared__ double cur[PO_TERMS], cand[PO_TERMS];
     __shared__ double T0[12], T[12], Tn[12];
     __shared__ double s_lambda, s_ni;
     __shared__ int s_flag, s_accepted, s_nactive;
     const int tid = threadIdx.x;
-    if (tid < 12) T0[tid] = pose_in[tid];
-    if (tid == 0) s_accepted = 0;
+    const bool staged = O <= PO_STAGE;
+    const double* points = g_points;
+    const double2* meas = g_meas;
+    uint8_t* active = g_active;
+    double* chi2 = g_chi2;
+    if (staged) {
+        for (int i = tid; i < O * 3; i += PO_THREADS) s_points[i] = g_points[i];
+        for (int o = tid; o < O; o += PO_THREADS) s_meas[o] = g_meas[o];
+        points = s_points; meas = s_meas; active = s_active; chi2 = s_chi2;
+    }
+    if (tid < 12) T0[tid] = T[tid] = pose_in[tid];
+    if (tid == 0) { s_accepted = 0; s_nactive = 0; }
     for (int o = tid; o < O; o += PO_THREADS) active[o] = 1;
     __syncthreads();
+    int nactive = O;
     double delta = prm.huber_delta;
     for (int round = 0; round < prm.rounds; round++) {
         if (tid < 12) T[tid] = T0[tid];                 // every round restarts from the frame's pose (frontend.py:360)
         __syncthreads();
-        po_evaluate(T, points, meas, active, O, cam, delta, chi2, sw, cur);
+        po_evaluate(T, points, meas, active, O, cam, delta, chi2, red, part, cur);
         if (tid == 0) {
             double dmax = 0.0;
             const int diag[6] = {0, 6, 11, 15, 18, 20};
             for (int i = 0; i < 6; i++) dmax = fmax(dmax, cur[diag[i]]);
             s_lambda = 1e-5 * fmax(dmax, 1e-12);        // tau * max diagonal
             s_ni = 2.0;
-            int n = 0;
-            for (int o = 0; o < O; o++) n += active[o];
-            s_nactive = n;
         }
         __syncthreads();
-        for (int it = 0; it < prm.iterations && s_nactive > 0; it++) {
+        for (int it = 0; it < prm.iterations && nactive > 0; it++) {
             bool ok = false;
             for (int trial = 0; trial < 10; trial++) {  // maxTrialsAfterFailure
                 // lane 0 proposes a step
@@ -204,7 +244,7 @@ __global__ __launch_bounds__(PO_THREADS) void pose_opt_kernel(const double* __re
                     __syncthreads();
                     continue;
                 }
-                po_evaluate(Tn, points, meas, active, O, cam, delta, chi2, sw, cand);
+                po_evaluate(Tn, points, meas, active, O, cam, delta, chi2, red, part, cand);
                 if (tid == 0) {
                     const double rho = (cur[27] - cand[27]) / scale;
                     if (rho > 0.0 && isfinite(cand[27])) {
@@ -230,17 +270,26 @@ __global__ __launch_bounds__(PO_THREADS) void pose_opt_kernel(const double* __re
             if (!ok) break;
         }
         // chi2 at the pose this round ended on, then the outlier / level decision (frontend.py:366-379)
-        po_evaluate(T, points, meas, active, O, cam, delta, chi2, sw, cand);
-        for (int o = tid; o < O; o += PO_THREADS) active[o] = chi2[o] <= prm.chi2_threshold ? 1 : 0;
+        po_evaluate(T, points, meas, active, O, cam, delta, chi2, red, part, cand);
+        int mine = 0;
+        for (int o = tid; o < O; o += PO_THREADS) {
+            const uint8_t in = chi2[o] <= prm.chi2_threshold ? 1 : 0;
+            active[o] = in;
+            mine += in;
+        }
+        if (mine) atomicAdd(&s_nactive, mine);          // integer: order does not matter
         if (round == 2) delta = 0.0;
         __syncthreads();
+        nactive = s_nactive;
+        __syncthreads();
+        if (tid == 0) s_nactive = 0;
     }
     if (tid < 12) pose_out[tid] = T[tid];
+    if (staged)
+        for (int o = tid; o < O; o += PO_THREADS) { g_active[o] = s_active[o]; g_chi2[o] = s_chi2[o]; }
     if (tid == 0) {
-        int n = 0;
-        for (int o = 0; o < O; o++) n += active[o];
-        stats[0] = n;              // inlier count: what _correct_current_pose returns (frontend.py:393)
-        stats[1] = s_accepted;     // accepted LM steps over all rounds
+        stats[0] = prm.rounds > 0 ? nactive : O;   // inlier count: what _correct_current_pose returns (frontend.py:393)
+        stats[1] = s_accepted;                      // accepted LM steps over all rounds
     }
 }
 

@@ -60,6 +60,11 @@ SIGNATURES = {
     "slam_pose_optimize_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double, c_double, c_double,
                                        c_double, c_int, c_int, c_double, c_double, c_void_p, c_void_p, c_void_p,
                                        c_void_p]),
+    "slam_bf_match_host": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_double,
+                                   c_void_p, c_void_p, c_void_p, c_void_p]),
+    "slam_pose_optimize_host_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double, c_double,
+                                            c_double, c_double, c_int, c_int, c_double, c_double, c_void_p, c_void_p,
+                                            c_void_p, c_void_p]),
     "slam_ba_reduce_f64": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
                                    c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_double,
                                    c_double, c_double, c_double, c_double, c_void_p, c_void_p, c_void_p, c_void_p,

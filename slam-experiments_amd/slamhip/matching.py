@@ -112,6 +112,23 @@ def _filter_device(ctx: Context, table: Top2Table, mode: int, param: float) -> T
     return k, mind.value
 
 
+def _match_host(ctx: Context, q: np.ndarray, t: Optional[np.ndarray], d_train: Optional[DeviceBuffer], m: int,
+                keep_query: Optional[DeviceBuffer], mode: int, param: float):
+    """One ``slam_bf_match_host`` call: upload, top-2 search, selection, download, one synchronisation."""
+    n = q.shape[0]
+    qi = np.empty(n, np.int32)
+    ti = np.empty(n, np.int32)
+    dist = np.empty(n, np.float32)
+    cnt = ctypes.c_int64(0)
+    check(ctx.lib.slam_bf_match_host(ctx.handle, q.ctypes.data if n else None, n,
+                                     t.ctypes.data if t is not None and m else None,
+                                     d_train.ptr if d_train is not None and m else None, m,
+                                     keep_query.ptr if keep_query is not None else None, mode, float(param),
+                                     qi.ctypes.data, ti.ctypes.data, dist.ctypes.data, ctypes.byref(cnt)))
+    c = cnt.value
+    return qi[:c], ti[:c], dist[:c]
+
+
 def match_arrays(source, query, dist_threshold: Optional[float] = None, ctx: Optional[Context] = None):
     """``BruteForceFeatureMatcher.match`` as arrays (``feature_matchers.py:36-44``).
 
@@ -121,43 +138,15 @@ def match_arrays(source, query, dist_threshold: Optional[float] = None, ctx: Opt
     ``dist_threshold`` filter keeps ``distance < max(2*min_dist, dist_threshold)``."""
     q, t = as_descriptors(query), as_descriptors(source)
     ctx = ctx or default_context()
-    n, m = q.shape[0], t.shape[0]
-    if n == 0 or m == 0:
-        return np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0, np.float32)
-    dq, dt = DeviceDescriptors(ctx, q), DeviceDescriptors(ctx, t)
-    table = Top2Table(ctx, n)
-    try:
-        knn2_device(ctx, dq.buf, n, dt.buf, m, table.idx, table.dist)
-        mode = MODE_MIN_DIST if dist_threshold else MODE_ALL   # `if dist_threshold and ...` (feature_matchers.py:41)
-        keep, _ = _filter_device(ctx, table, mode, float(dist_threshold or 0.0))
-        idx, dist = table.download()
-    finally:
-        table.free()
-        dq.free()
-        dt.free()
-    qi = np.nonzero(keep)[0].astype(np.int32)
-    return qi, idx[keep, 0], dist[keep, 0].astype(np.float32)
+    mode = MODE_MIN_DIST if dist_threshold else MODE_ALL   # `if dist_threshold and ...` (feature_matchers.py:41)
+    return _match_host(ctx, q, t, None, t.shape[0], None, mode, float(dist_threshold or 0.0))
 
 
 def ratio_test_arrays(query, train, ratio: float = 0.75, ctx: Optional[Context] = None):
     """knn=2 + Lowe ratio test: (queryIdx, trainIdx, distance) of queries with d0 < ratio * d1."""
     q, t = as_descriptors(query), as_descriptors(train)
     ctx = ctx or default_context()
-    n, m = q.shape[0], t.shape[0]
-    if n == 0 or m == 0:
-        return np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0, np.float32)
-    dq, dt = DeviceDescriptors(ctx, q), DeviceDescriptors(ctx, t)
-    table = Top2Table(ctx, n)
-    try:
-        knn2_device(ctx, dq.buf, n, dt.buf, m, table.idx, table.dist)
-        keep, _ = _filter_device(ctx, table, MODE_RATIO, ratio)
-        idx, dist = table.download()
-    finally:
-        table.free()
-        dq.free()
-        dt.free()
-    qi = np.nonzero(keep)[0].astype(np.int32)
-    return qi, idx[keep, 0], dist[keep, 0].astype(np.float32)
+    return _match_host(ctx, q, t, None, t.shape[0], None, MODE_RATIO, ratio)
 
 
 def cross_check_arrays(query, train, ctx: Optional[Context] = None):
@@ -231,24 +220,18 @@ class ResidentMatcher:
     def push(self, descriptors, dist_threshold: Optional[float] = None):
         """Match ``descriptors`` (current frame, query) against the previously pushed frame (train).
 
-        Returns (queryIdx, trainIdx, distance) like ``match_arrays``, or None for the first frame."""
-        cur = DeviceDescriptors(self.ctx, as_descriptors(descriptors))
+        Returns (queryIdx, trainIdx, distance) like ``match_arrays``, or None for the first frame.
+        One call into the library per frame: the rows go up once, into the buffer the next frame will
+        search as its train side."""
+        q = as_descriptors(descriptors)
+        cur = DeviceDescriptors(self.ctx, rows=q.shape[0])
         prev, self._last = self._last, cur
-        if prev is None:
-            return None
         try:
-            n, m = cur.rows, prev.rows
-            if n == 0 or m == 0:
-                return np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0, np.float32)
-            table = Top2Table(self.ctx, n)
-            try:
-                knn2_device(self.ctx, cur.buf, n, prev.buf, m, table.idx, table.dist)
-                mode = MODE_MIN_DIST if dist_threshold else MODE_ALL
-                keep, _ = _filter_device(self.ctx, table, mode, float(dist_threshold or 0.0))
-                idx, dist = table.download()
-            finally:
-                table.free()
+            mode = MODE_MIN_DIST if dist_threshold else MODE_ALL
+            out = _match_host(self.ctx, q, None, prev.buf if prev is not None else None,
+                              prev.rows if prev is not None else 0, cur.buf if q.shape[0] else None, mode,
+                              float(dist_threshold or 0.0))
         finally:
-            prev.free()
-        qi = np.nonzero(keep)[0].astype(np.int32)
-        return qi, idx[keep, 0], dist[keep, 0].astype(np.float32)
+            if prev is not None:
+                prev.free()
+        return None if prev is None else out

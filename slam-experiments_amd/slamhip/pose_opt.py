@@ -143,8 +143,8 @@ def optimize_pose_only(pose, points, meas, intrinsics, rounds: int = 4, iteratio
 def optimize_pose_only_device(pose, points, meas, intrinsics, rounds: int = 4, iterations: int = 10,
                               chi2_threshold: float = CHI2_THRESHOLD, huber_delta: float = HUBER_DELTA,
                               ctx: Optional[Context] = None) -> PoseOptResult:
-    """Same job as ``optimize_pose_only`` with the whole LM loop on the GPU: ONE kernel launch
-    (``slam_pose_optimize_f64``) instead of one launch + PCIe round trip per LM trial."""
+    """Same job as ``optimize_pose_only`` with the whole LM loop on the GPU: ONE kernel launch between one
+    upload and one download (``slam_pose_optimize_host_f64``) instead of one launch + PCIe round trip per LM trial."""
     import ctypes  # noqa: F401  (ctypes types come through the binding)
 
     from ._lib import check
@@ -159,25 +159,16 @@ def optimize_pose_only_device(pose, points, meas, intrinsics, rounds: int = 4, i
     if meas.shape[0] != O:
         raise ValueError("one measurement per point")
     fx, fy, cx, cy = (float(v) for v in intrinsics)
-    o = max(O, 1)
-    bufs = []
-    try:
-        d_in = ctx.upload(T0[:3, :4].reshape(12)); bufs.append(d_in)
-        d_pts = ctx.upload(points) if O else ctx.malloc(24); bufs.append(d_pts)
-        d_meas = ctx.upload(meas) if O else ctx.malloc(16); bufs.append(d_meas)
-        d_out = ctx.malloc(96); bufs.append(d_out)
-        d_inl = ctx.malloc(o); bufs.append(d_inl)
-        d_chi2 = ctx.malloc(o * 8); bufs.append(d_chi2)
-        d_stats = ctx.malloc(8); bufs.append(d_stats)
-        check(ctx.lib.slam_pose_optimize_f64(ctx.handle, d_in.ptr, d_pts.ptr, d_meas.ptr, O, fx, fy, cx, cy, int(rounds),
-                                             int(iterations), float(chi2_threshold), float(huber_delta), d_out.ptr,
-                                             d_inl.ptr, d_chi2.ptr, d_stats.ptr))
-        T = np.eye(4)
-        T[:3, :4] = d_out.download(np.float64, (3, 4))
-        inl = d_inl.download(np.uint8, (O,)).astype(bool) if O else np.zeros(0, bool)
-        chi2 = d_chi2.download(np.float64, (O,)) if O else np.zeros(0)
-        stats = d_stats.download(np.int32, (2,))
-    finally:
-        for b in bufs:
-            b.free()
-    return PoseOptResult(pose=T, inliers=inl, chi2=chi2, n_inliers=int(stats[0]), iterations=int(stats[1]))
+    T = np.eye(4)
+    out12 = np.empty(12, np.float64)
+    inl = np.zeros(O, np.uint8)
+    chi2 = np.zeros(O, np.float64)
+    stats = np.zeros(2, np.int32)
+    pin = np.ascontiguousarray(T0[:3, :4].reshape(12))
+    check(ctx.lib.slam_pose_optimize_host_f64(ctx.handle, pin.ctypes.data, points.ctypes.data if O else None,
+                                              meas.ctypes.data if O else None, O, fx, fy, cx, cy, int(rounds),
+                                              int(iterations), float(chi2_threshold), float(huber_delta),
+                                              out12.ctypes.data, inl.ctypes.data if O else None,
+                                              chi2.ctypes.data if O else None, stats.ctypes.data))
+    T[:3, :4] = out12.reshape(3, 4)
+    return PoseOptResult(pose=T, inliers=inl.astype(bool), chi2=chi2, n_inliers=int(stats[0]), iterations=int(stats[1]))

@@ -51,3 +51,63 @@ def test_two_contexts_are_independent(gpu_ctx):
         assert np.array_equal(ra[0], oracle.bf_knn_c(q, t, 2)[0]) and np.array_equal(rb[0], oracle.bf_knn_c(t, q, 2)[0])
     finally:
         a.close(); b.close()
+
+
+def test_host_buffer_entry_points(gpu_ctx):
+    """slam_bf_match_host / slam_bf_knn2_u256_host / slam_pose_optimize_host_f64: argument checks, the empty
+    cases, and agreement with the device-pointer entry points they wrap."""
+    from oracle import oracle
+
+    lib, ctx = gpu_ctx.lib, gpu_ctx
+    rng = np.random.default_rng(5)
+    q = rng.integers(0, 256, (37, 32), dtype=np.uint8)
+    t = rng.integers(0, 256, (53, 32), dtype=np.uint8)
+    qi, ti, di = np.empty(37, np.int32), np.empty(37, np.int32), np.empty(37, np.float32)
+    cnt = ctypes.c_int64(-1)
+    dt = ctx.upload(t)
+    args = (qi.ctypes.data, ti.ctypes.data, di.ctypes.data, ctypes.byref(cnt))
+    # both a host and a device train pointer, a bad mode, a missing count pointer, missing train rows
+    assert lib.slam_bf_match_host(ctx.handle, q.ctypes.data, 37, t.ctypes.data, dt.ptr, 53, None, 0, 0.0, *args) == -1
+    assert b"not both" in lib.slam_last_error()
+    assert lib.slam_bf_match_host(ctx.handle, q.ctypes.data, 37, t.ctypes.data, None, 53, None, 3, 0.0, *args) == -1
+    assert lib.slam_bf_match_host(ctx.handle, q.ctypes.data, 37, t.ctypes.data, None, 53, None, 0, 0.0, *args[:3], None) == -1
+    assert lib.slam_bf_match_host(ctx.handle, q.ctypes.data, 37, None, None, 53, None, 0, 0.0, *args) == -1
+    # empty sides: no matches, not an error
+    assert lib.slam_bf_match_host(ctx.handle, None, 0, t.ctypes.data, None, 53, None, 0, 0.0, *args) == 0 and cnt.value == 0
+    assert lib.slam_bf_match_host(ctx.handle, q.ctypes.data, 37, None, None, 0, None, 1, 30.0, *args) == 0 and cnt.value == 0
+    # host train, device train and the kept query rows give the same matches as the oracle
+    exp_i, exp_d = oracle.bf_knn_c(q, t, 2)
+    oq, ot, od = oracle.bf_match_c(t, q, 64.0)          # the reference filter, restated in C
+    dkeep = ctx.malloc(37 * 32)
+    for h_train, d_train in ((t.ctypes.data, None), (None, dt.ptr)):
+        assert lib.slam_bf_match_host(ctx.handle, q.ctypes.data, 37, h_train, d_train, 53, dkeep.ptr, 0, 0.0, *args) == 0
+        assert cnt.value == 37 and np.array_equal(qi, np.arange(37)) and np.array_equal(ti, exp_i[:, 0])
+        assert np.array_equal(di, exp_d[:, 0].astype(np.float32))
+        assert np.array_equal(dkeep.download(np.uint8, (37, 32)), q)
+        assert lib.slam_bf_match_host(ctx.handle, q.ctypes.data, 37, h_train, d_train, 53, None, 1, 64.0, *args) == 0
+        lim = max(2.0 * exp_d[:, 0].min(), 64.0)
+        sel = exp_d[:, 0] < lim
+        c = cnt.value
+        assert c == sel.sum() and np.array_equal(qi[:c], np.flatnonzero(sel)) and np.array_equal(ti[:c], exp_i[sel, 0])
+        assert np.array_equal(qi[:c], oq) and np.array_equal(ti[:c], ot) and np.array_equal(di[:c], od)
+    idx, dist = np.empty((37, 2), np.int32), np.empty((37, 2), np.int32)
+    assert lib.slam_bf_knn2_u256_host(ctx.handle, q.ctypes.data, 37, t.ctypes.data, 53, idx.ctypes.data, dist.ctypes.data) == 0
+    assert np.array_equal(idx, exp_i) and np.array_equal(dist, exp_d)
+    assert lib.slam_bf_knn2_u256_host(ctx.handle, q.ctypes.data, 37, None, 0, idx.ctypes.data, dist.ctypes.data) == 0
+    assert (idx == -1).all() and (dist == 2**31 - 1).all()
+    assert lib.slam_bf_knn2_u256_host(ctx.handle, q.ctypes.data, 37, None, 5, idx.ctypes.data, dist.ctypes.data) == -1
+    # a larger call after a small one grows the arena; results stay right
+    q2 = rng.integers(0, 256, (5000, 32), dtype=np.uint8)
+    i2, d2 = np.empty((5000, 2), np.int32), np.empty((5000, 2), np.int32)
+    assert lib.slam_bf_knn2_u256_host(ctx.handle, q2.ctypes.data, 5000, t.ctypes.data, 53, i2.ctypes.data, d2.ctypes.data) == 0
+    e2i, e2d = oracle.bf_knn_c(q2, t, 2)
+    assert np.array_equal(i2, e2i) and np.array_equal(d2, e2d)
+    dt.free(); dkeep.free()
+    # pose optimisation on host buffers: null pointers are rejected, O == 0 returns the input pose
+    pose = np.eye(4)[:3].reshape(12).copy()
+    out, stats = np.empty(12), np.zeros(2, np.int32)
+    assert lib.slam_pose_optimize_host_f64(ctx.handle, pose.ctypes.data, None, None, 5, 1.0, 1.0, 0.0, 0.0, 4, 10, 35.9, 1.0,
+                                           out.ctypes.data, None, None, stats.ctypes.data) == -1
+    assert lib.slam_pose_optimize_host_f64(ctx.handle, pose.ctypes.data, None, None, 0, 1.0, 1.0, 0.0, 0.0, 4, 10, 35.9, 1.0,
+                                           out.ctypes.data, None, None, stats.ctypes.data) == 0
+    assert np.array_equal(out, pose) and stats[0] == 0

@@ -40,7 +40,9 @@ def test_pose_only_recovers_pose_and_rejects_outliers(gpu_ctx):
     dev = Backend().optimize_pose(T_init, X, meas, FX, FY, CX, CY, on_device=True)
     # the one-launch device loop follows the same schedule as the host-driven one
     assert np.allclose(dev.pose, res.pose, rtol=0, atol=1e-8) and np.array_equal(dev.inliers, res.inliers)
-    assert dev.n_inliers == res.n_inliers and abs(dev.iterations - res.iterations) <= 3   # a last negligible step may flip
+    assert dev.n_inliers == res.n_inliers
+    # at convergence cost differences are rounding noise, so the last one or two steps of each of the 4 rounds may flip
+    assert abs(dev.iterations - res.iterations) <= 8
     assert np.allclose(dev.chi2, res.chi2, rtol=1e-6, atol=1e-6)
     # truncation biases the pixels by ~0.5 px; the pose must still land within a few mm / mrad
     d = res.pose @ np.linalg.inv(T_true)

@@ -18,6 +18,14 @@ for n in (200, 2000, 20000):
         for _ in range(50):
             f()
         print(f"n={n:6d} {name:28s} {(time.perf_counter() - t0) / 50 * 1e3:8.3f} ms per call")
+big_q = rng.integers(0, 256, (65536, 32), dtype=np.uint8); big_t = rng.integers(0, 256, (65536, 32), dtype=np.uint8)
+for _ in range(3):
+    bf.knn_match_arrays(big_q, big_t, 2)
+t0 = time.perf_counter()
+for _ in range(20):
+    bf.knn_match_arrays(big_q, big_t, 2)
+dt = (time.perf_counter() - t0) / 20
+print(f"n= 65536 knn_match_arrays(k=2) on host buffers (PCIe inclusive) {dt * 1e3:8.3f} ms per call = {65536 * 65536 / dt:.3e} pairs/s")
 rm = slamhip.ResidentMatcher()
 fr = [rng.integers(0, 256, (200, 32), dtype=np.uint8) for _ in range(60)]
 rm.push(fr[0])
