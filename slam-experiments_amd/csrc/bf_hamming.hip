@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256) void bf_fill_none_kernel(int N, int2* __restri
 struct bf_plan {
     int R;        // queries per lane
     int qblocks;  // grid.x
-    int chunk;    // train rows per chunk (multiple of the LDS tile)
+    int chunk;    // train rows per chunk (a multiple of the LDS tile, or of 32 rows for frame-sized inputs)
     int S;        // grid.y
 };
 
@@ -377,6 +377,16 @@ static void plan_for(const slam_ctx* ctx, int64_t N, int64_t M, int R, int block
     if (S < 1) S = 1;
     int64_t chunk = (M + S - 1) / S;
     chunk = (chunk + SLAM_TILE_ROWS - 1) / SLAM_TILE_ROWS * SLAM_TILE_ROWS;
+    // Frame-sized problems (fewer 256-row blocks than CUs; the reference matches <= 200 x 200, slam.py:23) are
+    // latency-bound on one block's serial scan: cut the train rows into sub-tile chunks, one block per CU.
+    // Measured: 200 x 200 21.6 -> 9.1 us, 1000 x 1000 27.1 -> 12.7 us, 2000 x 2000 28.5 -> 19.5 us; from
+    // 4096 x 4096 up finer chunks only add cold starts and merges (34 -> 46-91 us), so those keep whole tiles.
+    if (!g_blocks_per_cu && (int64_t)p->qblocks * tiles < ctx->num_cu) {
+        int64_t want = ctx->num_cu / p->qblocks;
+        int64_t c2 = (M + want - 1) / want;
+        c2 = (c2 + 31) / 32 * 32;
+        if (c2 < chunk) chunk = c2;
+    }
     p->chunk = (int)chunk;
     p->S = (int)((M + chunk - 1) / chunk);
 }

@@ -1,0 +1,17 @@
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "slam-experiments_amd"))
+from slamhip.device import default_context
+ctx = default_context(); lib, h = ctx.lib, ctx.handle
+rng = np.random.default_rng(1)
+for n, m in ((200, 200), (1000, 1000), (2000, 2000), (4096, 4096), (20000, 20000), (8192, 65536), (65536, 65536)):
+    q = ctx.upload(rng.integers(0, 256, (n, 32), dtype=np.uint8)); t = ctx.upload(rng.integers(0, 256, (m, 32), dtype=np.uint8))
+    oi, od = ctx.malloc(n * 8), ctx.malloc(n * 8)
+    f = lambda: lib.slam_bf_knn2_u256(h, q.ptr, n, t.ptr, m, 0, oi.ptr, od.ptr)
+    for _ in range(30): f()
+    ctx.sync(); ctx.timer_start()
+    reps = 200 if n < 60000 else 50
+    for _ in range(reps): f()
+    print(f"gran={os.environ.get('SLAM_BF_CHUNK_GRAN','-')} {n}x{m}: {ctx.timer_stop() / reps * 1e3:9.1f} us", flush=True)
+    for b in (q, t, oi, od): b.free()
