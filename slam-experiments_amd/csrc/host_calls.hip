@@ -4,6 +4,8 @@
 // microseconds and what a call costs is the number of PCIe round trips and synchronisations around them.
 // Each function here packs its inputs into one pinned staging block, does ONE host-to-device copy,
 // launches everything on the context stream, does ONE device-to-host copy and synchronises once.
+// The staging block belongs to the context, so these calls serialise per context (ctypes drops the GIL:
+// the reference's tracking thread and a backend thread may both be in here).
 //   slam_bf_knn2_u256_host       cv2.BFMatcher.knnMatch(k=2) (the search behind feature_matchers.py:39)
 //   slam_bf_match_host           BruteForceFeatureMatcher.match (feature_matchers.py:36-44)
 //   slam_pose_optimize_host_f64  Frontend._correct_current_pose (frontend.py:298-393)
@@ -18,6 +20,7 @@ extern "C" int slam_bf_knn2_u256_host(slam_ctx* ctx, const uint8_t* h_query, int
     SLAM_REQUIRE(N >= 0 && M >= 0 && N <= (1ll << 28) && M <= (1ll << 28), "bad sizes N=%lld M=%lld", (long long)N, (long long)M);
     if (N == 0) return SLAM_OK;
     SLAM_REQUIRE(h_query && h_idx && h_dist && (h_train || M == 0), "slam_bf_knn2_u256_host: null host pointer");
+    std::lock_guard<std::mutex> lk(ctx->io_mu);
     SLAM_HIP(hipSetDevice(ctx->device));
     const uint64_t qbytes = (uint64_t)N * SLAM_DESC_BYTES, tbytes = (uint64_t)M * SLAM_DESC_BYTES;
     const uint64_t off_t = align_up(qbytes, 256), off_i = off_t + align_up(tbytes, 256);
@@ -49,6 +52,7 @@ extern "C" int slam_bf_match_host(slam_ctx* ctx, const uint8_t* h_query, int64_t
     SLAM_REQUIRE(N == 0 || h_query, "slam_bf_match_host: null h_query");
     SLAM_REQUIRE(N == 0 || (h_query_idx && h_train_idx && h_distance), "slam_bf_match_host: null output pointer");
     SLAM_REQUIRE(M == 0 || h_train || d_train, "slam_bf_match_host: no train descriptors");
+    std::lock_guard<std::mutex> lk(ctx->io_mu);
     SLAM_HIP(hipSetDevice(ctx->device));
     const uint64_t qbytes = (uint64_t)N * SLAM_DESC_BYTES, tbytes = h_train ? (uint64_t)M * SLAM_DESC_BYTES : 0;
     if (N == 0 || M == 0) {
@@ -109,6 +113,7 @@ extern "C" int slam_pose_optimize_host_f64(slam_ctx* ctx, const double* h_pose_i
     SLAM_REQUIRE(O >= 0 && O <= (1 << 24), "O=%lld out of range [0, 2^24]", (long long)O);
     SLAM_REQUIRE(h_pose_in && h_pose_out && h_stats && (O == 0 || (h_points && h_meas && h_inlier && h_chi2)),
                  "slam_pose_optimize_host_f64: null host pointer");
+    std::lock_guard<std::mutex> lk(ctx->io_mu);
     SLAM_HIP(hipSetDevice(ctx->device));
     // in: [pose 12 | points 3O | pad | meas 2O]   out: [pose 12 | chi2 O | stats (2 x int32) | inlier u8[O]]
     const uint64_t o = (uint64_t)O;

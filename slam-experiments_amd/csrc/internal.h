@@ -23,6 +23,7 @@ struct slam_ctx {
     uint64_t io_dev_bytes = 0;
     void* io_host = nullptr;                        // pinned host staging for the same (grow-only)
     uint64_t io_host_bytes = 0;
+    std::mutex io_mu;                               // one host-buffer call at a time per context (they share the arena)
     // profiling of the dominant kernel
     int prof_on = 0;
     static const int PROF_MAX = 4096;

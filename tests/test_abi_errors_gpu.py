@@ -111,3 +111,36 @@ def test_host_buffer_entry_points(gpu_ctx):
     assert lib.slam_pose_optimize_host_f64(ctx.handle, pose.ctypes.data, None, None, 0, 1.0, 1.0, 0.0, 0.0, 4, 10, 35.9, 1.0,
                                            out.ctypes.data, None, None, stats.ctypes.data) == 0
     assert np.array_equal(out, pose) and stats[0] == 0
+
+
+def test_host_calls_from_two_threads_share_a_context(gpu_ctx):
+    """ctypes releases the GIL during a call; the frontend thread and a backend thread of the reference
+    (slam.py:26-35) may use the default context at once.  Host-buffer calls serialise on the context."""
+    import threading
+
+    import slamhip
+    from oracle import oracle
+
+    rng = np.random.default_rng(9)
+    sets = [(rng.integers(0, 256, (150 + 37 * i, 32), dtype=np.uint8), rng.integers(0, 256, (90 + 11 * i, 32), dtype=np.uint8))
+            for i in range(4)]
+    expect = [oracle.bf_match_c(t, q, 40.0) for q, t in sets]
+    errors = []
+
+    def worker(k):
+        try:
+            for it in range(60):
+                q, t = sets[(k + it) % 4]
+                got = slamhip.match_arrays(t, q, 40.0, ctx=gpu_ctx)
+                exp = expect[(k + it) % 4]
+                if not all(np.array_equal(a, b) for a, b in zip(got, exp)):
+                    errors.append((k, it))
+        except Exception as exc:   # noqa: BLE001
+            errors.append(exc)
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(3)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors[:3]
