@@ -90,3 +90,49 @@ class Backend:
         fn = _ba.bundle_adjust_device if on_device else _ba.bundle_adjust
         return fn(poses, points, obs_pose_idx, obs_point_idx, meas, (fx, fy, cx, cy), iterations, fixed_poses,
                   huber_delta, ctx=self.ctx)
+
+    def optimize_map(self, map_, fx, fy, cx, cy, iterations: int = 10, huber_delta: float = 5.991 ** 0.5,
+                     n_fixed: int = 1, min_observations: int = 2, on_device: bool = True):
+        """``optimize`` over the reference's own containers: the active keyframes of a ``Map``
+        (``backend.py:10-53``, at most ``NUM_ACTIVE_KEYFRAMES`` = 7) and the landmarks they observe.
+
+        Reads ``map_._active_keyframes`` / ``map_._active_landmarks`` directly — the public getters return deep
+        copies (``backend.py:43-53``), which cannot be written back.  An observation is a ``Feature`` in a
+        landmark's ``observations`` (``primitives.py:133-147``) whose ``frame`` is an active keyframe; its pixel is
+        ``Feature.position`` (int-truncated, ``primitives.py:110-112``).  The ``n_fixed`` oldest keyframes (by
+        ``keyframe_id``) hold the gauge.  Landmarks seen fewer than ``min_observations`` times in the window are
+        left alone.  Results go back through ``Frame.set_pose`` (as ``type(pose).from_matrix(T)`` when the pose
+        class has it, e.g. ``jaxlie.SE3``, else the 4x4 matrix) and ``MapPoint.set_position``.
+        Returns ``slamhip.ba.BAResult`` or None if the window holds nothing to optimise."""
+        kfs = sorted(map_._active_keyframes.values(), key=lambda f: f.keyframe_id)
+        if len(kfs) < 2:
+            return None
+        kf_index = {id(f): k for k, f in enumerate(kfs)}
+        points, landmarks, op, ol, meas = [], [], [], [], []
+        for mp in map_._active_landmarks.values():
+            obs = [(kf_index[id(ft.frame)], ft) for ft in list(mp.get_observations()) if id(ft.frame) in kf_index]
+            if len(obs) < min_observations or len({k for k, _ in obs}) != len(obs):
+                continue                                   # too few views, or two features of one frame on one landmark
+            l = len(landmarks)
+            landmarks.append(mp)
+            points.append(np.asarray(mp.position, np.float64))
+            for k, ft in sorted(obs, key=lambda kv: kv[0]):
+                op.append(k)
+                ol.append(l)
+                meas.append(np.asarray(ft.position, np.float64))
+        if not landmarks:
+            return None
+
+        def as_matrix(pose):
+            return np.asarray(pose.as_matrix() if hasattr(pose, "as_matrix") else pose, np.float64)
+
+        T = np.stack([as_matrix(f.pose) for f in kfs])
+        res = self.optimize(T, np.stack(points), np.asarray(op, np.int32), np.asarray(ol, np.int32), np.stack(meas),
+                            fx, fy, cx, cy, iterations=iterations, fixed_poses=tuple(range(min(n_fixed, len(kfs)))),
+                            huber_delta=huber_delta, on_device=on_device)
+        for k, f in enumerate(kfs[n_fixed:], start=n_fixed):
+            make = getattr(type(f.pose), "from_matrix", None)
+            f.set_pose(make(res.poses[k]) if make is not None else res.poses[k])
+        for l, mp in enumerate(landmarks):
+            mp.set_position(res.points[l])
+        return res

@@ -200,3 +200,64 @@ def test_schur_problem_rejects_bad_input(gpu_ctx):
         SchurProblem(gpu_ctx, 2, 3, [0, 0], [1, 1], np.zeros((2, 2)), (FX, FY, CX, CY))      # duplicate (pose, point)
     with pytest.raises(ValueError):
         SchurProblem(gpu_ctx, 2, 3, [0, 2], [1, 1], np.zeros((2, 2)), (FX, FY, CX, CY))      # pose index out of range
+
+
+def test_backend_optimizes_a_map_in_place(gpu_ctx):
+    """Backend.optimize_map on duck-typed stand-ins for the reference's Map / Frame / MapPoint / Feature
+    (attribute names of backend.py:10-53 and primitives.py:93-197; the real classes need cv2 / jaxlie)."""
+    from backend import Backend
+    from slamhip.pose_opt import se3_exp
+
+    class Pose:
+        def __init__(self, T): self.T = np.array(T)
+        def as_matrix(self): return self.T
+        @classmethod
+        def from_matrix(cls, T): return cls(T)
+
+    class Frame:
+        def __init__(self, kid, pose): self.keyframe_id, self.pose, self.features = kid, pose, []
+        def set_pose(self, pose): self.pose = pose
+
+    class MapPoint:
+        def __init__(self, pos): self.position, self.observations = pos, set()
+        def get_observations(self): return self.observations
+        def set_position(self, p): self.position = p
+
+    class Feature:
+        def __init__(self, frame, px, mp): self.frame, self.position, self.map_point = frame, px, mp
+
+    class Map:
+        def __init__(self): self._active_keyframes, self._active_landmarks = {}, {}
+
+    rng = np.random.default_rng(11)
+    K, L = 7, 250
+    T, X = _scene(rng, K, L)
+    m = Map()
+    frames = [Frame(10 + k, Pose(T[k] if k < 2 else se3_exp(rng.normal(0, 0.004, 6)) @ T[k])) for k in range(K)]   # two exact: gauge + scale
+    for f in reversed(frames):                            # dict order is not keyframe order
+        m._active_keyframes[f.keyframe_id] = f
+    stale = Frame(3, Pose(np.eye(4)))                     # a keyframe that left the window still holds observations
+    for l in range(L):
+        mp = MapPoint(X[l] + rng.normal(0, 0.03, 3))
+        seen = rng.uniform(size=K) < (0.75 if l else 0.0) # landmark 0 is seen by nobody in the window
+        for k in np.flatnonzero(seen):
+            px = (_project(T[k], X[l:l + 1])[0] + rng.normal(0, 0.2, 2)).astype(np.int32)   # Feature.position truncates
+            mp.observations.add(Feature(frames[k], px, mp))
+        mp.observations.add(Feature(stale, np.zeros(2, np.int32), mp))
+        m._active_landmarks[l] = mp
+    before_pose = [f.pose.T.copy() for f in frames]
+    before_pts = np.stack([m._active_landmarks[l].position for l in range(L)])
+    res = Backend().optimize_map(m, FX, FY, CX, CY, iterations=10, n_fixed=2)
+    assert res is not None and res.iterations > 0 and res.chi2_final < 0.2 * res.chi2_initial
+    assert np.array_equal(frames[0].pose.T, before_pose[0]) and np.array_equal(frames[1].pose.T, before_pose[1])   # gauge keyframes untouched
+    assert all(isinstance(f.pose, Pose) for f in frames)
+    err0 = np.mean([np.linalg.norm((before_pose[k] @ np.linalg.inv(T[k]))[:3, 3]) for k in range(2, K)])
+    err1 = np.mean([np.linalg.norm((frames[k].pose.T @ np.linalg.inv(T[k]))[:3, 3]) for k in range(2, K)])
+    assert err1 < err0                                                            # poses moved towards the truth
+    after_pts = np.stack([m._active_landmarks[l].position for l in range(L)])
+    assert np.array_equal(after_pts[0], before_pts[0])                            # unobserved landmark left alone
+    moved = np.linalg.norm(after_pts - before_pts, axis=1) > 0
+    assert moved[1:].mean() > 0.9
+    # a window with a single keyframe has nothing to optimise
+    m2 = Map(); m2._active_keyframes[1] = frames[0]
+    assert Backend().optimize_map(m2, FX, FY, CX, CY) is None
