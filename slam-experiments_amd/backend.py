@@ -136,3 +136,25 @@ class Backend:
         for l, mp in enumerate(landmarks):
             mp.set_position(res.points[l])
         return res
+
+    def correct_frame_pose(self, frame, fx, fy, cx, cy, rounds: int = 4, iterations: int = 10) -> int:
+        """``Frontend._correct_current_pose`` (``frontend.py:298-393``) on the reference's own ``Frame``: one
+        edge per feature that has a map point (``:318-320``), landmark position and int pixel as the edge data
+        (``:340,348``), four rounds of ten LM iterations with the chi2 gate and the Huber kernel of
+        ``optimize_pose``; then the frame takes the refined pose (``:384``), outlier features lose their map
+        point and their flag is cleared (``:388-391``).  Returns the inlier count like the reference (``:393``)."""
+        features = [ft for ft in frame.features if ft.map_point]
+        if not features:
+            return 0
+        points = np.stack([np.asarray(ft.map_point.position, np.float64) for ft in features])
+        pixels = np.stack([np.asarray(ft.position, np.float64) for ft in features])
+        pose = frame.pose
+        T0 = np.asarray(pose.as_matrix() if hasattr(pose, "as_matrix") else pose, np.float64)
+        res = self.optimize_pose(T0, points, pixels, fx, fy, cx, cy, rounds=rounds, iterations=iterations)
+        make = getattr(type(pose), "from_matrix", None)
+        frame.set_pose(make(res.pose) if make is not None else res.pose)
+        for ft, inlier in zip(features, res.inliers):
+            if not inlier:
+                ft.map_point = None
+            ft.is_outlier = False
+        return res.n_inliers

@@ -261,3 +261,45 @@ def test_backend_optimizes_a_map_in_place(gpu_ctx):
     # a window with a single keyframe has nothing to optimise
     m2 = Map(); m2._active_keyframes[1] = frames[0]
     assert Backend().optimize_map(m2, FX, FY, CX, CY) is None
+
+
+def test_backend_corrects_a_frame_pose_in_place(gpu_ctx):
+    """Backend.correct_frame_pose on stand-ins with the attribute layout of primitives.py:93-197: the frame gets
+    the refined pose, outlier features lose their map point (frontend.py:384-393)."""
+    from backend import Backend
+    from slamhip.pose_opt import se3_exp
+
+    class Pose:
+        def __init__(self, T): self.T = np.array(T)
+        def as_matrix(self): return self.T
+        @classmethod
+        def from_matrix(cls, T): return cls(T)
+
+    class MapPoint:
+        def __init__(self, pos): self.position = pos
+
+    class Feature:
+        def __init__(self, px, mp): self.position, self.map_point, self.is_outlier = px, mp, False
+
+    class Frame:
+        def __init__(self, pose): self.pose, self.features = pose, []
+        def set_pose(self, pose): self.pose = pose
+
+    rng = np.random.default_rng(21)
+    T, X = _scene(rng, 1, 180)
+    frame = Frame(Pose(se3_exp([0.01, -0.02, 0.01, 0.05, 0.04, -0.06]) @ T[0]))
+    px = (_project(T[0], X) + rng.normal(0, 0.3, (180, 2)))
+    bad = np.arange(0, 180, 9)
+    px[bad] += 70.0
+    for l in range(180):
+        frame.features.append(Feature(px[l].astype(np.int32), MapPoint(X[l])))
+    frame.features += [Feature(np.zeros(2, np.int32), None) for _ in range(20)]      # features without a map point
+    n = Backend().correct_frame_pose(frame, FX, FY, CX, CY)
+    assert n == 180 - len(bad) and isinstance(frame.pose, Pose)
+    d = frame.pose.T @ np.linalg.inv(T[0])
+    assert np.linalg.norm(d[:3, 3]) < 0.02
+    assert all(frame.features[l].map_point is None for l in bad)
+    assert all(frame.features[l].map_point is not None for l in range(180) if l not in set(bad))
+    assert not any(ft.is_outlier for ft in frame.features)
+    empty = Frame(Pose(np.eye(4)))
+    assert Backend().correct_frame_pose(empty, FX, FY, CX, CY) == 0
