@@ -202,7 +202,8 @@ SLAM_API int slam_pose_optimize_host_f64(slam_ctx* ctx, const double* h_pose_in,
  * linearise all O observations, Schur-eliminate the L points with damping `lambda`, and leave on device:
  *   d_rec  [O,SLAM_BA_REC] per-observation blocks (Hpl, Y = Hpl E, ...), d_E [L,9] = (Hll+lambda I)^-1,
  *   d_bl [L,3], d_Hpp [K,21] (upper triangles), d_bp [K,6], d_ybl [K,6] = sum Y bl, d_cost [K] (robust cost
- *   per pose), d_W [K,K,36] with W[k1,k2] = sum_l Y_(k1,l) Hpl_(k2,l)^T for k1 <= k2 (other blocks untouched).
+ *   per pose), d_W [K,K,36] with W[k1,k2] = sum_l Y_(k1,l) Hpl_(k2,l)^T for k1 <= k2 (other blocks untouched),
+ *   d_hll_diag [L,3] = diagonal of the undamped Hll (optional, may be null; for the initial damping).
  * The caller assembles S = blockdiag(Hpp + lambda I) - W (symmetric), rhs = -bp + ybl, solves for dp [K,6] and
  * calls slam_ba_backsub_f64 for the point updates dl [L,3].
  * Index tables (int32, device): obs_pose/obs_point [O]; pt_ptr [L+1]/pt_obs [O] = observations grouped by
@@ -215,7 +216,12 @@ SLAM_API int slam_ba_reduce_f64(slam_ctx* ctx, const double* d_poses, int64_t K,
                                 const int32_t* d_ps_ptr, const int32_t* d_ps_obs, const int32_t* d_lookup,
                                 double fx, double fy, double cx, double cy, double huber_delta, double lambda,
                                 double* d_rec, double* d_E, double* d_bl, double* d_Hpp, double* d_bp,
-                                double* d_ybl, double* d_cost, double* d_W);
+                                double* d_ybl, double* d_cost, double* d_W, double* d_hll_diag);
+/* Robust cost of a candidate state only, per pose (d_cost [K]); same tables as slam_ba_reduce_f64. */
+SLAM_API int slam_ba_cost_f64(slam_ctx* ctx, const double* d_poses, int64_t K, const double* d_points,
+                              const int32_t* d_obs_point, const double* d_meas, const int32_t* d_ps_ptr,
+                              const int32_t* d_ps_obs, double fx, double fy, double cx, double cy,
+                              double huber_delta, double* d_cost);
 SLAM_API int slam_ba_backsub_f64(slam_ctx* ctx, int64_t L, const int32_t* d_pt_ptr, const int32_t* d_pt_obs,
                                  const int32_t* d_obs_pose, const double* d_rec, const double* d_E,
                                  const double* d_bl, const double* d_dp, double* d_dl);

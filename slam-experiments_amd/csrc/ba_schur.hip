@@ -100,7 +100,8 @@ __global__ __launch_bounds__(BA_THREADS) void ba_obs_kernel(const double* __rest
 __global__ __launch_bounds__(BA_THREADS) void ba_point_kernel(const int* __restrict__ pt_ptr,
                                                               const int* __restrict__ pt_obs, int L, double lam,
                                                               double* __restrict__ rec, double* __restrict__ E,
-                                                              double* __restrict__ bl) {
+                                                              double* __restrict__ bl,
+                                                              double* __restrict__ hll_diag /*[L,3] or null*/) {
     const int l = blockIdx.x * BA_THREADS + threadIdx.x;
     if (l >= L) return;
     double h[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
@@ -126,6 +127,11 @@ __global__ __launch_bounds__(BA_THREADS) void ba_point_kernel(const int* __restr
     for (int k = 0; k < 9; k++) E[(size_t)l * 9 + k] = e[k];
 #pragma unroll
     for (int k = 0; k < 3; k++) bl[(size_t)l * 3 + k] = b[k];
+    if (hll_diag) {
+        hll_diag[(size_t)l * 3] = h[0];
+        hll_diag[(size_t)l * 3 + 1] = h[3];
+        hll_diag[(size_t)l * 3 + 2] = h[5];
+    }
     for (int i = a0; i < a1; i++) {
         double* r = rec + (size_t)pt_obs[i] * BA_REC;
 #pragma unroll
@@ -244,13 +250,64 @@ __global__ __launch_bounds__(BA_THREADS) void ba_backsub_kernel(const int* __res
     for (int c = 0; c < 3; c++) dl[(size_t)l * 3 + c] = seen ? e[c * 3] * t[0] + e[c * 3 + 1] * t[1] + e[c * 3 + 2] * t[2] : 0.0;
 }
 
+// robust cost only (an LM trial needs nothing else from the candidate state): one block per pose
+__global__ __launch_bounds__(BA_THREADS) void ba_cost_kernel(const double* __restrict__ poses,
+                                                             const double* __restrict__ points,
+                                                             const int* __restrict__ obs_point,
+                                                             const double2* __restrict__ meas,
+                                                             const int* __restrict__ ps_ptr,
+                                                             const int* __restrict__ ps_obs, ba_cam cam, double delta,
+                                                             double* __restrict__ cost /*[K]*/) {
+    __shared__ double sw[4][1];
+    __shared__ double out[1];
+    const int k = blockIdx.x;
+    const double* P = poses + (size_t)k * 12;
+    double acc[1] = {0.0};
+    for (int i = ps_ptr[k] + threadIdx.x; i < ps_ptr[k + 1]; i += BA_THREADS) {
+        const int o = ps_obs[i];
+        const double* p = points + (size_t)obs_point[o] * 3;
+        const double X = P[0] * p[0] + P[1] * p[1] + P[2] * p[2] + P[3];
+        const double Y = P[4] * p[0] + P[5] * p[1] + P[6] * p[2] + P[7];
+        const double Z = P[8] * p[0] + P[9] * p[1] + P[10] * p[2] + P[11];
+        const double2 m = meas[o];
+        const double e0 = m.x - (cam.fx * X + cam.cx * Z) / Z;
+        const double e1 = m.y - (cam.fy * Y + cam.cy * Z) / Z;
+        const double c2 = e0 * e0 + e1 * e1;
+        double rho = c2;
+        if (delta > 0.0) {
+            const double en = sqrt(c2);
+            if (en > delta) rho = 2.0 * delta * en - delta * delta;
+        }
+        acc[0] += rho;
+    }
+    ba_block_sum<1>(acc, sw, out);
+    if (threadIdx.x == 0) cost[k] = out[0];
+}
+
+extern "C" int slam_ba_cost_f64(slam_ctx* ctx, const double* d_poses, int64_t K, const double* d_points,
+                                const int32_t* d_obs_point, const double* d_meas, const int32_t* d_ps_ptr,
+                                const int32_t* d_ps_obs, double fx, double fy, double cx, double cy,
+                                double huber_delta, double* d_cost) {
+    SLAM_REQUIRE(ctx, "slam_ba_cost_f64: null ctx");
+    SLAM_REQUIRE(K >= 1 && K <= 1024, "bad K");
+    SLAM_REQUIRE(d_poses && d_points && d_obs_point && d_meas && d_ps_ptr && d_ps_obs && d_cost,
+                 "slam_ba_cost_f64: null device pointer");
+    SLAM_REQUIRE(((uintptr_t)d_meas & 15) == 0, "d_meas must be 16-byte aligned");
+    SLAM_HIP(hipSetDevice(ctx->device));
+    const ba_cam cam = {fx, fy, cx, cy};
+    ba_cost_kernel<<<(unsigned)K, BA_THREADS, 0, ctx->stream>>>(d_poses, d_points, d_obs_point, (const double2*)d_meas,
+                                                                d_ps_ptr, d_ps_obs, cam, huber_delta, d_cost);
+    SLAM_HIP(hipGetLastError());
+    return SLAM_OK;
+}
+
 extern "C" int slam_ba_reduce_f64(slam_ctx* ctx, const double* d_poses, int64_t K, const double* d_points,
                                   int64_t L, const int32_t* d_obs_pose, const int32_t* d_obs_point,
                                   const double* d_meas, int64_t O, const int32_t* d_pt_ptr, const int32_t* d_pt_obs,
                                   const int32_t* d_ps_ptr, const int32_t* d_ps_obs, const int32_t* d_lookup,
                                   double fx, double fy, double cx, double cy, double huber_delta, double lambda,
                                   double* d_rec, double* d_E, double* d_bl, double* d_Hpp, double* d_bp,
-                                  double* d_ybl, double* d_cost, double* d_W) {
+                                  double* d_ybl, double* d_cost, double* d_W, double* d_hll_diag) {
     SLAM_REQUIRE(ctx, "slam_ba_reduce_f64: null ctx");
     SLAM_REQUIRE(K >= 1 && K <= 1024 && L >= 1 && O >= 0 && L <= (1 << 28) && O <= (1 << 28), "bad sizes");
     SLAM_REQUIRE(d_poses && d_points && d_obs_pose && d_obs_point && d_meas && d_pt_ptr && d_pt_obs && d_ps_ptr &&
@@ -263,7 +320,7 @@ extern "C" int slam_ba_reduce_f64(slam_ctx* ctx, const double* d_poses, int64_t 
         ba_obs_kernel<<<(unsigned)((O + BA_THREADS - 1) / BA_THREADS), BA_THREADS, 0, ctx->stream>>>(
             d_poses, d_points, d_obs_pose, d_obs_point, (const double2*)d_meas, (int)O, cam, huber_delta, d_rec);
     ba_point_kernel<<<(unsigned)((L + BA_THREADS - 1) / BA_THREADS), BA_THREADS, 0, ctx->stream>>>(
-        d_pt_ptr, d_pt_obs, (int)L, lambda, d_rec, d_E, d_bl);
+        d_pt_ptr, d_pt_obs, (int)L, lambda, d_rec, d_E, d_bl, d_hll_diag);
     ba_pose_kernel<<<(unsigned)K, BA_THREADS, 0, ctx->stream>>>(d_ps_ptr, d_ps_obs, d_obs_point, d_rec, d_bl, d_Hpp,
                                                                  d_bp, d_ybl, d_cost);
     ba_pair_kernel<<<dim3((unsigned)K, (unsigned)K), BA_THREADS, 0, ctx->stream>>>(d_ps_ptr, d_ps_obs, d_obs_point,

@@ -68,7 +68,9 @@ SIGNATURES = {
     "slam_ba_reduce_f64": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
                                    c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_double,
                                    c_double, c_double, c_double, c_double, c_void_p, c_void_p, c_void_p, c_void_p,
-                                   c_void_p, c_void_p, c_void_p, c_void_p]),
+                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "slam_ba_cost_f64": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double,
+                                 c_double, c_double, c_double, c_double, c_void_p]),
     "slam_ba_backsub_f64": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p]),
     "slam_comm_unique_id": (c_int, [c_void_p]),

@@ -171,9 +171,14 @@ class SchurProblem:
         self.d_poses, self.d_points = ctx.malloc(K * 96), ctx.malloc(L * 24)
         o = max(O, 1)
         self.d_rec, self.d_E, self.d_bl = ctx.malloc(o * self.REC * 8), ctx.malloc(L * 72), ctx.malloc(L * 24)
-        self.d_Hpp, self.d_bp, self.d_ybl, self.d_cost = ctx.malloc(K * 168), ctx.malloc(K * 48), ctx.malloc(K * 48), ctx.malloc(K * 8)
-        self.d_W = ctx.malloc(K * K * 288)
+        # every reduced block in one allocation, so a reduction comes back in one download
+        self._n_out = K * (21 + 6 + 6 + 1) + K * K * 36
+        self.d_out = ctx.malloc(self._n_out * 8)
+        self.d_Hpp, self.d_bp = self.d_out.view(0, K * 168), self.d_out.view(K * 168, K * 48)
+        self.d_ybl, self.d_cost = self.d_out.view(K * 216, K * 48), self.d_out.view(K * 264, K * 8)
+        self.d_W = self.d_out.view(K * 272, K * K * 288)
         self.d_dp, self.d_dl = ctx.malloc(K * 48), ctx.malloc(L * 24)
+        self.d_hll = ctx.malloc(L * 24)
         self._iu = np.triu_indices(6)
 
     def reduce(self, poses12, points, huber_delta: float, lam: float):
@@ -185,25 +190,32 @@ class SchurProblem:
             c.handle, self.d_poses.ptr, K, self.d_points.ptr, self.L, self.d_op.ptr, self.d_ol.ptr, self.d_meas.ptr,
             self.O, self.d_pt_ptr.ptr, self.d_pt_obs.ptr, self.d_ps_ptr.ptr, self.d_ps_obs.ptr, self.d_lookup.ptr,
             self.fx, self.fy, self.cx, self.cy, float(huber_delta), float(lam), self.d_rec.ptr, self.d_E.ptr,
-            self.d_bl.ptr, self.d_Hpp.ptr, self.d_bp.ptr, self.d_ybl.ptr, self.d_cost.ptr, self.d_W.ptr))
-        tri = self.d_Hpp.download(np.float64, (K, 21))
-        bp = self.d_bp.download(np.float64, (K, 6))
-        ybl = self.d_ybl.download(np.float64, (K, 6))
-        cost = float(self.d_cost.download(np.float64, (K,)).sum())
-        W = self.d_W.download(np.float64, (K, K, 6, 6))
+            self.d_bl.ptr, self.d_Hpp.ptr, self.d_bp.ptr, self.d_ybl.ptr, self.d_cost.ptr, self.d_W.ptr, self.d_hll.ptr))
+        out = self.d_out.download(np.float64, (self._n_out,))
+        tri, bp, ybl = out[:K * 21].reshape(K, 21), out[K * 21:K * 27].reshape(K, 6), out[K * 27:K * 33].reshape(K, 6)
+        cost = float(out[K * 33:K * 34].sum())
+        W = out[K * 34:].reshape(K, K, 6, 6)
         Hpp = np.zeros((K, 6, 6))
         Hpp[:, self._iu[0], self._iu[1]] = tri
         Hpp[:, self._iu[1], self._iu[0]] = tri
         S = np.zeros((K, K, 6, 6))
-        for k1 in range(K):
-            S[k1, k1] = Hpp[k1] + lam * np.eye(6) - W[k1, k1]
-            for k2 in range(k1 + 1, K):
-                S[k1, k2] = -W[k1, k2]
-                S[k2, k1] = -W[k1, k2].T
+        k1, k2 = np.triu_indices(K, 1)
+        S[k1, k2] = -W[k1, k2]
+        S[k2, k1] = -W[k1, k2].transpose(0, 2, 1)
+        kk = np.arange(K)
+        S[kk, kk] = Hpp + lam * np.eye(6) - W[kk, kk]
         return S, -bp + ybl, bp, cost
 
     def cost(self, poses12, points, huber_delta: float) -> float:
-        return self.reduce(poses12, points, huber_delta, 1.0)[3]
+        """Robust cost at a candidate state (``slam_ba_cost_f64``); leaves the blocks of the last ``reduce`` alone
+        but replaces the device copy of the state."""
+        c, K = self.ctx, self.K
+        self.d_poses.upload(np.ascontiguousarray(poses12, np.float64).reshape(K, 12))
+        self.d_points.upload(np.ascontiguousarray(points, np.float64).reshape(self.L, 3))
+        self._check(c.lib.slam_ba_cost_f64(c.handle, self.d_poses.ptr, K, self.d_points.ptr, self.d_ol.ptr, self.d_meas.ptr,
+                                           self.d_ps_ptr.ptr, self.d_ps_obs.ptr, self.fx, self.fy, self.cx, self.cy,
+                                           float(huber_delta), self.d_cost.ptr))
+        return float(self.d_cost.download(np.float64, (K,)).sum())
 
     def back_substitute(self, dp):
         """dp [K,6] -> (dl [L,3], bl [L,3]) for the system of the last ``reduce``."""
@@ -218,10 +230,7 @@ class SchurProblem:
         tri = self.d_Hpp.download(np.float64, (self.K, 21))
         d = tri[:, [0, 6, 11, 15, 18, 20]].max(initial=0.0)
         if self.O:
-            rec = self.d_rec.download(np.float64, (self.O, self.REC))
-            hl = np.zeros((self.L, 3))
-            np.add.at(hl, self.d_ol.download(np.int32, (self.O,)), rec[:, [63, 66, 68]])
-            d = max(d, hl.max(initial=0.0))
+            d = max(d, self.d_hll.download(np.float64, (self.L, 3)).max(initial=0.0))
         return float(d)
 
     def free(self) -> None:

@@ -39,7 +39,7 @@ for K, L in ((7, 1400), (16, 5000), (32, 20000)):
         lib.slam_ba_reduce_f64(h, sp.d_poses.ptr, K, sp.d_points.ptr, L, sp.d_op.ptr, sp.d_ol.ptr, sp.d_meas.ptr, sp.O,
                                sp.d_pt_ptr.ptr, sp.d_pt_obs.ptr, sp.d_ps_ptr.ptr, sp.d_ps_obs.ptr, sp.d_lookup.ptr,
                                FX, FY, CX, CY, 0.0, 1.0, sp.d_rec.ptr, sp.d_E.ptr, sp.d_bl.ptr, sp.d_Hpp.ptr, sp.d_bp.ptr,
-                               sp.d_ybl.ptr, sp.d_cost.ptr, sp.d_W.ptr)
+                               sp.d_ybl.ptr, sp.d_cost.ptr, sp.d_W.ptr, sp.d_hll.ptr)
     ms = ctx.timer_stop() / 20
     sp.free()
     print(f"K={K} L={L} O={len(op)}: reduce kernels {ms*1e3:.1f} us/call; " +
