@@ -16,5 +16,5 @@ for n, m in SIZES:
     ctx.sync(); ctx.timer_start()
     reps = 200 if n < 60000 else (50 if n < 100000 else 3)
     for _ in range(reps): f()
-    print(f"direct_max={os.environ.get('SLAM_BF_DIRECT_MAX','-')} bpc={os.environ.get('SLAM_BF_DIRECT_BPC','-')} {n}x{m}: {(ms := ctx.timer_stop() / reps) * 1e3:9.1f} us  {n * m / ms / 1e9:8.1f} Gpairs/ms-normalised = {n * m / (ms * 1e-3):.3e} pairs/s", flush=True)
+    print(f"{n}x{m}: {(ms := ctx.timer_stop() / reps) * 1e3:9.1f} us  {n * m / ms / 1e9:8.1f} Gpairs/ms-normalised = {n * m / (ms * 1e-3):.3e} pairs/s", flush=True)
     for b in (q, t, oi, od): b.free()
