@@ -286,3 +286,29 @@ def test_train_set_larger_than_one_key_range(gpu_ctx):
     assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist)
     assert idx[0, 0] == m - 1 and dist[0, 0] == 0
     assert idx[1].tolist() == [5, (1 << 23) + 9] and dist[1].tolist() == [0, 0]
+
+
+@pytest.mark.parametrize("n,m", [(4096, 4096), (4097, 100), (100, 4097), (16384, 300), (16385, 300), (1, 4096), (255, 33)])
+def test_host_call_path_boundaries(gpu_ctx, n, m):
+    """match_arrays / ratio_test_arrays / knn_match_arrays across the internal switch points of the host-buffer
+    calls (zero-copy up to 4096 rows a side, one-workgroup filter up to 16384 queries, sub-tile train chunks)."""
+    import slamhip
+    from oracle import oracle
+
+    rng = np.random.default_rng(n * 31 + m)
+    t = rng.integers(0, 256, (m, 32), dtype=np.uint8)
+    q = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    dup = rng.choice(n, max(1, n // 50), replace=False)           # planted near-duplicates so filters keep something
+    q[dup] = t[rng.integers(0, m, len(dup))]
+    q[dup, 0] ^= 0x11
+    ei, ed = oracle.bf_knn_c(q, t, 2, threads=8)
+    gi, gd = slamhip.knn_match_arrays(q, t, 2, ctx=gpu_ctx)
+    assert np.array_equal(gi, ei) and np.array_equal(gd, ed)
+    for thr in (None, 30.0, 400.0):
+        got = slamhip.match_arrays(t, q, thr, ctx=gpu_ctx)
+        exp = oracle.bf_match_c(t, q, thr, threads=8)
+        assert all(np.array_equal(a, b) for a, b in zip(got, exp)), thr
+    keep = oracle.bf_ratio_c(ei, ed, 0.75)
+    rq, rt, rd = slamhip.ratio_test_arrays(q, t, 0.75, ctx=gpu_ctx)
+    assert np.array_equal(rq, np.flatnonzero(keep)) and np.array_equal(rt, ei[keep, 0])
+    assert np.array_equal(rd, ed[keep, 0].astype(np.float32))
