@@ -11,6 +11,8 @@ from __future__ import annotations
 from abc import ABC, abstractmethod
 from typing import Optional, Sequence
 
+from itertools import repeat
+
 import numpy as np
 
 from slamhip import matching as _m
@@ -43,7 +45,9 @@ def _make_dmatch(q: int, t: int, d: float, img: int = 0):
 
 
 def _to_dmatches(qi: np.ndarray, ti: np.ndarray, dist: np.ndarray) -> list:
-    return [_make_dmatch(q, t, d) for q, t, d in zip(qi.tolist(), ti.tolist(), dist.tolist())]
+    # .tolist() already yields Python ints / floats; map() keeps the per-object cost to the constructor call
+    cls = _CvDMatch if _CvDMatch is not None else DMatch
+    return list(map(cls, qi.tolist(), ti.tolist(), repeat(0, len(qi)), dist.tolist()))
 
 
 class FeatureMatcher(ABC):
