@@ -113,7 +113,7 @@ __device__ bool po_solve(const double* s, const double* b, double lam, double* x
 // One block-wide evaluation at pose T: sums[0..20] = upper H, [21..26] = b, [27] = robust chi2 over the
 // active edges; chi2[o] = e.e for every edge.  Every thread returns with the sums in `out` (shared).
 // points / meas / active / chi2 are generic pointers: the LDS copies when the problem is staged, else global.
-__device__ void po_evaluate(const double* T, const double* points, const double2* meas, const uint8_t* active, int O,
+__device__ __forceinline__ void po_evaluate(const double* T, const double* points, const double2* meas, const uint8_t* active, int O,
                             po_cam cam, double delta, double* chi2, double* red, double* part, double* out) {
     double acc[PO_TERMS];
 #pragma unroll
@@ -174,37 +174,23 @@ __device__ void po_evaluate(const double* T, const double* points, const double2
     __syncthreads();
 }
 
-__global__ __launch_bounds__(PO_THREADS) void pose_opt_kernel(const double* __restrict__ pose_in,
-                                                              const double* __restrict__ g_points,
-                                                              const double2* __restrict__ g_meas, int O, po_cam cam,
-                                                              po_params prm, double* __restrict__ pose_out,
-                                                              uint8_t* __restrict__ g_active,
-                                                              double* __restrict__ g_chi2, int* __restrict__ stats) {
-    // A frame has <= 200 edges (slam.py:23): the whole problem lives in LDS (24.5 KiB) and no evaluation touches
-    // global memory.  Larger problems run the same code on the global arrays.
-    __shared__ double s_points[PO_STAGE * 3];
-    __shared__ double2 s_meas[PO_STAGE];
-    __shared__ double s_chi2[PO_STAGE];
-    __shared__ uint8_t s_active[PO_STAGE];
-    __shared__ double red[(PO_TERMS / 2) * PO_THREADS];
-    __shared__ double part[PO_TERMS * 8];
-    __shared__ double cur[PO_TERMS], cand[PO_TERMS];
-    __shared__ double T0[12], T[12], Tn[12];
-    __shared__ double s_lambda, s_ni;
-    __shared__ int s_flag, s_accepted, s_nactive;
+struct po_shared {
+    double red[(PO_TERMS / 2) * PO_THREADS];
+    double part[PO_TERMS * 8];
+    double cur[PO_TERMS], cand[PO_TERMS];
+    double T0[12], T[12], Tn[12];
+    double lambda, ni;
+    int flag, accepted, nactive;
+};
+
+// The LM loop proper.  Force-inlined into both call sites of the kernel so that the staged instance addresses
+// points / meas / active / chi2 as LDS (ds_read) and the large-problem instance as global memory, instead of
+// both going through flat loads on generic pointers.
+__device__ __forceinline__ int po_run(po_shared& sh, const double* points, const double2* meas, uint8_t* active,
+                                      double* chi2, int O, po_cam cam, po_params prm) {
     const int tid = threadIdx.x;
-    const bool staged = O <= PO_STAGE;
-    const double* points = g_points;
-    const double2* meas = g_meas;
-    uint8_t* active = g_active;
-    double* chi2 = g_chi2;
-    if (staged) {
-        for (int i = tid; i < O * 3; i += PO_THREADS) s_points[i] = g_points[i];
-        for (int o = tid; o < O; o += PO_THREADS) s_meas[o] = g_meas[o];
-        points = s_points; meas = s_meas; active = s_active; chi2 = s_chi2;
-    }
-    if (tid < 12) T0[tid] = T[tid] = pose_in[tid];
-    if (tid == 0) { s_accepted = 0; s_nactive = 0; }
+    double* red = sh.red; double* part = sh.part; double* cur = sh.cur; double* cand = sh.cand;
+    double* T0 = sh.T0; double* T = sh.T; double* Tn = sh.Tn;
     for (int o = tid; o < O; o += PO_THREADS) active[o] = 1;
     __syncthreads();
     int nactive = O;
@@ -217,8 +203,8 @@ __global__ __launch_bounds__(PO_THREADS) void pose_opt_kernel(const double* __re
             double dmax = 0.0;
             const int diag[6] = {0, 6, 11, 15, 18, 20};
             for (int i = 0; i < 6; i++) dmax = fmax(dmax, cur[diag[i]]);
-            s_lambda = 1e-5 * fmax(dmax, 1e-12);        // tau * max diagonal
-            s_ni = 2.0;
+            sh.lambda = 1e-5 * fmax(dmax, 1e-12);        // tau * max diagonal
+            sh.ni = 2.0;
         }
         __syncthreads();
         for (int it = 0; it < prm.iterations && nactive > 0; it++) {
@@ -227,20 +213,20 @@ __global__ __launch_bounds__(PO_THREADS) void pose_opt_kernel(const double* __re
                 // lane 0 proposes a step
                 if (tid == 0) {
                     double dx[6];
-                    s_flag = po_solve(cur, cur + 21, s_lambda, dx) ? 1 : 0;
-                    if (s_flag) {
+                    sh.flag = po_solve(cur, cur + 21, sh.lambda, dx) ? 1 : 0;
+                    if (sh.flag) {
                         po_apply_update(dx, T, Tn);
                         double scale = 1e-3;
-                        for (int i = 0; i < 6; i++) scale += dx[i] * (s_lambda * dx[i] - cur[21 + i]);
+                        for (int i = 0; i < 6; i++) scale += dx[i] * (sh.lambda * dx[i] - cur[21 + i]);
                         cand[0] = scale;                // parked until the evaluation overwrites cand
                     }
                 }
                 __syncthreads();
-                const int solved = s_flag;
+                const int solved = sh.flag;
                 const double scale = cand[0];
-                __syncthreads();                        // everybody has read s_flag / cand[0] before lane 0 moves on
+                __syncthreads();                        // everybody has read sh.flag / cand[0] before lane 0 moves on
                 if (!solved) {
-                    if (tid == 0) { s_lambda *= s_ni; s_ni *= 2.0; }
+                    if (tid == 0) { sh.lambda *= sh.ni; sh.ni *= 2.0; }
                     __syncthreads();
                     continue;
                 }
@@ -251,18 +237,18 @@ __global__ __launch_bounds__(PO_THREADS) void pose_opt_kernel(const double* __re
                         for (int i = 0; i < 12; i++) T[i] = Tn[i];
                         for (int i = 0; i < PO_TERMS; i++) cur[i] = cand[i];
                         const double g = 2.0 * rho - 1.0;
-                        s_lambda *= fmax(1.0 / 3.0, fmin(1.0 - g * g * g, 2.0 / 3.0));
-                        s_ni = 2.0;
-                        s_accepted++;
-                        s_flag = 2;
+                        sh.lambda *= fmax(1.0 / 3.0, fmin(1.0 - g * g * g, 2.0 / 3.0));
+                        sh.ni = 2.0;
+                        sh.accepted++;
+                        sh.flag = 2;
                     } else {
-                        s_lambda *= s_ni;
-                        s_ni *= 2.0;
-                        s_flag = isfinite(s_lambda) ? 1 : 3;
+                        sh.lambda *= sh.ni;
+                        sh.ni *= 2.0;
+                        sh.flag = isfinite(sh.lambda) ? 1 : 3;
                     }
                 }
                 __syncthreads();
-                const int verdict = s_flag;
+                const int verdict = sh.flag;
                 __syncthreads();                        // read before the next trial's lane 0 overwrites it
                 if (verdict == 2) { ok = true; break; }
                 if (verdict == 3) break;
@@ -277,19 +263,45 @@ __global__ __launch_bounds__(PO_THREADS) void pose_opt_kernel(const double* __re
             active[o] = in;
             mine += in;
         }
-        if (mine) atomicAdd(&s_nactive, mine);          // integer: order does not matter
+        if (mine) atomicAdd(&sh.nactive, mine);          // integer: order does not matter
         if (round == 2) delta = 0.0;
         __syncthreads();
-        nactive = s_nactive;
+        nactive = sh.nactive;
         __syncthreads();
-        if (tid == 0) s_nactive = 0;
+        if (tid == 0) sh.nactive = 0;
     }
-    if (tid < 12) pose_out[tid] = T[tid];
-    if (staged)
+    return nactive;
+}
+
+__global__ __launch_bounds__(PO_THREADS) void pose_opt_kernel(const double* __restrict__ pose_in,
+                                                              const double* __restrict__ g_points,
+                                                              const double2* __restrict__ g_meas, int O, po_cam cam,
+                                                              po_params prm, double* __restrict__ pose_out,
+                                                              uint8_t* __restrict__ g_active,
+                                                              double* __restrict__ g_chi2, int* __restrict__ stats) {
+    // A frame has <= 200 edges (slam.py:23): the whole problem lives in LDS (24.5 KiB) and no evaluation touches
+    // global memory.  Larger problems run the same code on the global arrays.
+    __shared__ double s_points[PO_STAGE * 3];
+    __shared__ double2 s_meas[PO_STAGE];
+    __shared__ double s_chi2[PO_STAGE];
+    __shared__ uint8_t s_active[PO_STAGE];
+    __shared__ po_shared sh;
+    const int tid = threadIdx.x;
+    if (tid < 12) sh.T0[tid] = sh.T[tid] = pose_in[tid];
+    if (tid == 0) { sh.accepted = 0; sh.nactive = 0; }
+    int nactive;
+    if (O <= PO_STAGE) {
+        for (int i = tid; i < O * 3; i += PO_THREADS) s_points[i] = g_points[i];
+        for (int o = tid; o < O; o += PO_THREADS) s_meas[o] = g_meas[o];
+        nactive = po_run(sh, s_points, s_meas, s_active, s_chi2, O, cam, prm);
         for (int o = tid; o < O; o += PO_THREADS) { g_active[o] = s_active[o]; g_chi2[o] = s_chi2[o]; }
+    } else {
+        nactive = po_run(sh, g_points, g_meas, g_active, g_chi2, O, cam, prm);
+    }
+    if (tid < 12) pose_out[tid] = sh.T[tid];
     if (tid == 0) {
         stats[0] = prm.rounds > 0 ? nactive : O;   // inlier count: what _correct_current_pose returns (frontend.py:393)
-        stats[1] = s_accepted;                      // accepted LM steps over all rounds
+        stats[1] = sh.accepted;                     // accepted LM steps over all rounds
     }
 }
 
