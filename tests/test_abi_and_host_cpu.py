@@ -114,3 +114,85 @@ def test_poses_to_rt12():
     T = np.arange(32, dtype=float).reshape(2, 4, 4)
     p = slamhip.poses_to_rt12(T)
     assert p.shape == (2, 12) and p[0].tolist() == list(range(12)) and p[1][3] == 19.0
+
+
+def test_backend_container_glue_without_gpu(monkeypatch):
+    """Backend.optimize_map / correct_frame_pose: what is read from and written back to the reference's
+    containers (attribute layout of backend.py:10-53, primitives.py:93-197).  The GPU solvers are replaced by
+    recorders, so this checks the host logic only."""
+    import backend
+    from slamhip.ba import BAResult
+    from slamhip.pose_opt import PoseOptResult
+
+    class Pose:
+        def __init__(self, T): self.T = np.array(T, float)
+        def as_matrix(self): return self.T
+        @classmethod
+        def from_matrix(cls, T): return cls(T)
+
+    class Frame:
+        def __init__(self, kid, pose): self.keyframe_id, self.pose, self.features = kid, pose, []
+        def set_pose(self, pose): self.pose = pose
+
+    class MapPoint:
+        def __init__(self, pos): self.position, self.observations = np.array(pos, float), set()
+        def get_observations(self): return self.observations
+        def set_position(self, p): self.position = p
+
+    class Feature:
+        def __init__(self, frame, px, mp): self.frame, self.position, self.map_point, self.is_outlier = frame, np.array(px, np.int32), mp, True
+
+    class Map:
+        def __init__(self): self._active_keyframes, self._active_landmarks = {}, {}
+
+    def T(x):
+        M = np.eye(4); M[0, 3] = x
+        return M
+
+    f = [Frame(7, Pose(T(7))), Frame(3, Pose(T(3))), Frame(5, Pose(T(5)))]
+    stale = Frame(1, Pose(T(1)))
+    m = Map()
+    for fr in f:
+        m._active_keyframes[fr.keyframe_id] = fr
+    a, b, c, d = MapPoint([1, 1, 1]), MapPoint([2, 2, 2]), MapPoint([3, 3, 3]), MapPoint([4, 4, 4])
+    a.observations |= {Feature(f[0], (10, 11), a), Feature(f[1], (12, 13), a), Feature(stale, (0, 0), a)}
+    b.observations |= {Feature(f[2], (20, 21), b)}                                  # one view in the window: skipped
+    c.observations |= {Feature(f[1], (30, 31), c), Feature(f[1], (32, 33), c)}      # two features of one frame: skipped
+    d.observations |= {Feature(f[2], (40, 41), d), Feature(f[1], (42, 43), d), Feature(f[0], (44, 45), d)}
+    for i, mp in enumerate((a, b, c, d)):
+        m._active_landmarks[i] = mp
+    seen = {}
+
+    def fake_optimize(self, poses, points, op, ol, meas, fx, fy, cx, cy, iterations=10, fixed_poses=(0,), huber_delta=0.0,
+                      on_device=True):
+        seen.update(poses=poses.copy(), points=points.copy(), op=op.copy(), ol=ol.copy(), meas=meas.copy(), fixed=fixed_poses)
+        return BAResult(poses=poses + 100.0, points=points + 0.5, chi2_initial=2.0, chi2_final=1.0, iterations=1)
+
+    monkeypatch.setattr(backend.Backend, "optimize", fake_optimize)
+    res = backend.Backend().optimize_map(m, 1.0, 1.0, 0.0, 0.0, n_fixed=1)
+    assert res.iterations == 1 and seen["fixed"] == (0,)
+    assert [P[0, 3] for P in seen["poses"]] == [3.0, 5.0, 7.0]                      # keyframes by ascending keyframe_id
+    assert np.array_equal(seen["points"], [[1, 1, 1], [4, 4, 4]])                   # landmarks a and d only
+    assert seen["op"].tolist() == [0, 2, 0, 1, 2] and seen["ol"].tolist() == [0, 0, 1, 1, 1]
+    assert seen["meas"].tolist() == [[12, 13], [10, 11], [42, 43], [40, 41], [44, 45]]
+    assert f[1].pose.T[0, 3] == 3.0                                                 # fixed keyframe keeps its pose object
+    assert f[2].pose.T[0, 3] == 105.0 and f[0].pose.T[0, 3] == 107.0 and isinstance(f[0].pose, Pose)
+    assert np.array_equal(a.position, [1.5, 1.5, 1.5]) and np.array_equal(d.position, [4.5, 4.5, 4.5])
+    assert np.array_equal(b.position, [2, 2, 2]) and np.array_equal(c.position, [3, 3, 3])
+    one = Map(); one._active_keyframes[3] = f[1]
+    assert backend.Backend().optimize_map(one, 1.0, 1.0, 0.0, 0.0) is None
+
+    # correct_frame_pose: edges from features with a map point, outliers lose it, flags cleared (frontend.py:318-393)
+    fr = Frame(9, Pose(T(0)))
+    fr.features = [Feature(fr, (1, 2), a), Feature(fr, (3, 4), None), Feature(fr, (5, 6), d)]
+
+    def fake_pose(self, pose, points, pixels, fx, fy, cx, cy, rounds=4, iterations=10, on_device=True):
+        seen.update(pp=points.copy(), px=pixels.copy())
+        return PoseOptResult(pose=T(42), inliers=np.array([True, False]), chi2=np.zeros(2), n_inliers=1, iterations=3)
+
+    monkeypatch.setattr(backend.Backend, "optimize_pose", fake_pose)
+    assert backend.Backend().correct_frame_pose(fr, 1.0, 1.0, 0.0, 0.0) == 1
+    assert seen["px"].tolist() == [[1, 2], [5, 6]] and np.array_equal(seen["pp"], [a.position, d.position])
+    assert fr.pose.T[0, 3] == 42.0 and fr.features[0].map_point is a and fr.features[2].map_point is None
+    assert not fr.features[0].is_outlier and not fr.features[2].is_outlier and fr.features[1].is_outlier
+    assert backend.Backend().correct_frame_pose(Frame(1, Pose(T(0))), 1.0, 1.0, 0.0, 0.0) == 0
