@@ -15,6 +15,7 @@ from typing import Optional, Sequence
 
 import numpy as np
 
+from ._lib import check
 from .device import Context, default_context
 from .pose_opt import se3_exp
 from .reproj import ReprojProblem, poses_to_rt12
@@ -140,7 +141,6 @@ class SchurProblem:
     REC = 73   # SLAM_BA_REC
 
     def __init__(self, ctx: Context, K: int, L: int, obs_pose, obs_point, meas, intrinsics):
-        from ._lib import check
         self._check = check
         self.ctx = ctx
         op = np.ascontiguousarray(obs_pose, np.int32).reshape(-1)
