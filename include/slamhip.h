@@ -183,7 +183,8 @@ SLAM_API int slam_pose_optimize_f64(slam_ctx* ctx, const double* d_pose_in, cons
  * one call.  Query rows h_query [N,32]; train rows either h_train [M,32] (host) or d_train (device, e.g. the
  * previous frame kept by an earlier call) - exactly one of them when M > 0.  If d_query_keep is non-null the
  * query rows are uploaded there (32*N bytes, caller-allocated with slam_malloc) so the next frame can pass it
- * as d_train.  mode/param as slam_bf_match_filter.  Outputs (caller-allocated, N entries each): the kept
+ * as d_train.  mode/param as slam_bf_match_filter, plus mode 3 = crossCheck (cv2.BFMatcher(normType,
+ * crossCheck=True).match; the reverse search runs in the same call, param unused).  Outputs (caller-allocated, N entries each): the kept
  * matches in ascending query order as query index, train index and distance (float32, integer-valued like
  * cv2's); *h_count = how many.  N == 0 or M == 0: no matches, not an error. */
 SLAM_API int slam_bf_match_host(slam_ctx* ctx, const uint8_t* h_query, int64_t N, const uint8_t* h_train,

@@ -175,15 +175,8 @@ __global__ __launch_bounds__(256) void cross_emit_kernel(const unsigned long lon
     if ((threadIdx.x & 63) == 0 && kept) atomicAdd(&s->count, (unsigned long long)kept);
 }
 
-extern "C" int slam_bf_cross_check(slam_ctx* ctx, const int32_t* d_rev_idx, const int32_t* d_rev_dist, int64_t M,
-                                   int64_t N, int32_t* d_out_idx, int32_t* d_out_dist, int64_t* h_count) {
-    SLAM_REQUIRE(ctx, "slam_bf_cross_check: null ctx");
-    SLAM_REQUIRE(N >= 0 && M >= 0 && N <= (1ll << 30) && M <= (1ll << 30), "bad sizes");
-    if (h_count) *h_count = 0;
-    if (N == 0) return SLAM_OK;
-    SLAM_REQUIRE(d_out_idx && d_out_dist && (M == 0 || (d_rev_idx && d_rev_dist)),
-                 "slam_bf_cross_check: null device pointer");
-    SLAM_HIP(hipSetDevice(ctx->device));
+int slam_cross_launch(slam_ctx* ctx, const int32_t* d_rev_idx, const int32_t* d_rev_dist, int64_t M, int64_t N,
+                      int32_t* d_out_idx, int32_t* d_out_dist) {
     filter_scratch* s = nullptr;
     if (int rc = filter_scratch_ptr(ctx, &s)) return rc;
     void* ws = nullptr;
@@ -196,8 +189,21 @@ extern "C" int slam_bf_cross_check(slam_ctx* ctx, const int32_t* d_rev_idx, cons
             (const int2*)d_rev_idx, (const int2*)d_rev_dist, (int)M, (int)N, slot);
     cross_emit_kernel<<<(unsigned)((N + 255) / 256), 256, 0, ctx->stream>>>(slot, (int)N, d_out_idx, d_out_dist, s);
     SLAM_HIP(hipGetLastError());
+    return SLAM_OK;
+}
+
+extern "C" int slam_bf_cross_check(slam_ctx* ctx, const int32_t* d_rev_idx, const int32_t* d_rev_dist, int64_t M,
+                                   int64_t N, int32_t* d_out_idx, int32_t* d_out_dist, int64_t* h_count) {
+    SLAM_REQUIRE(ctx, "slam_bf_cross_check: null ctx");
+    SLAM_REQUIRE(N >= 0 && M >= 0 && N <= (1ll << 30) && M <= (1ll << 30), "bad sizes");
+    if (h_count) *h_count = 0;
+    if (N == 0) return SLAM_OK;
+    SLAM_REQUIRE(d_out_idx && d_out_dist && (M == 0 || (d_rev_idx && d_rev_dist)),
+                 "slam_bf_cross_check: null device pointer");
+    SLAM_HIP(hipSetDevice(ctx->device));
+    if (int rc = slam_cross_launch(ctx, d_rev_idx, d_rev_dist, M, N, d_out_idx, d_out_dist)) return rc;
     filter_scratch h;
-    SLAM_HIP(hipMemcpyAsync(&h, s, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    SLAM_HIP(hipMemcpyAsync(&h, ctx->scratch, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
     SLAM_HIP(hipStreamSynchronize(ctx->stream));
     if (h_count) *h_count = (int64_t)h.count;
     return SLAM_OK;

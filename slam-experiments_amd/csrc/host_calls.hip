@@ -57,7 +57,7 @@ extern "C" int slam_bf_match_host(slam_ctx* ctx, const uint8_t* h_query, int64_t
     SLAM_REQUIRE(h_count, "slam_bf_match_host: null h_count");
     *h_count = 0;
     SLAM_REQUIRE(N >= 0 && M >= 0 && N <= (1ll << 28) && M <= (1ll << 28), "bad sizes N=%lld M=%lld", (long long)N, (long long)M);
-    SLAM_REQUIRE(mode >= 0 && mode <= 2, "mode %d not in {0,1,2}", mode);
+    SLAM_REQUIRE(mode >= 0 && mode <= 3, "mode %d not in {0,1,2,3}", mode);
     SLAM_REQUIRE(!(h_train && d_train), "pass the train descriptors either as h_train or as d_train, not both");
     SLAM_REQUIRE(N == 0 || h_query, "slam_bf_match_host: null h_query");
     SLAM_REQUIRE(N == 0 || (h_query_idx && h_train_idx && h_distance), "slam_bf_match_host: null output pointer");
@@ -74,8 +74,11 @@ extern "C" int slam_bf_match_host(slam_ctx* ctx, const uint8_t* h_query, int64_t
         return SLAM_OK;
     }
     // device arena: [query | train | idx int32[N,2] | dist int32[N,2] | keep u8[N]]; staging mirrors it
+    // (crossCheck, mode 3: | reverse tables int32[M,2] x 2 | idx int32[N] | dist int32[N])
     const uint64_t off_t = align_up(qbytes, 256), off_i = off_t + align_up(tbytes, 256);
-    const uint64_t off_d = off_i + (uint64_t)N * 8, off_k = off_d + (uint64_t)N * 8, total = align_up(off_k + N, 256);
+    const uint64_t off_d = off_i + (uint64_t)N * 8, off_k = off_d + (uint64_t)N * 8;
+    const uint64_t total = mode == 3 ? align_up(off_i + (uint64_t)M * 16, 256) + align_up((uint64_t)N * 8, 256)
+                                     : align_up(off_k + N, 256);
     void *dev = nullptr, *host = nullptr;
     if (int rc = slam_io_arena(ctx, total, total, &dev, &host)) return rc;
     uint8_t* hb = (uint8_t*)host;
@@ -95,6 +98,31 @@ extern "C" int slam_bf_match_host(slam_ctx* ctx, const uint8_t* h_query, int64_t
         SLAM_HIP(hipMemcpyAsync(db, hb, off_t + tbytes, hipMemcpyHostToDevice, ctx->stream));
     }
     const void* dt = h_train ? (const void*)(io + off_t) : d_train;
+    if (mode == 3) {
+        // cv2.BFMatcher(crossCheck=True).match: the reverse search (train rows as queries) stays on the device,
+        // only the per-query (idx, dist) pair comes back
+        int32_t* rev_idx = (int32_t*)(db + off_i);
+        int32_t* rev_dist = (int32_t*)(db + off_i + (uint64_t)M * 8);
+        const uint64_t off_o = align_up(off_i + (uint64_t)M * 16, 256);
+        int32_t* o_idx = (int32_t*)(io + off_o);
+        int32_t* o_dist = (int32_t*)(io + off_o + (uint64_t)N * 4);
+        if (int rc = slam_bf_knn2_u256(ctx, dt, M, dq, N, 0, rev_idx, rev_dist)) return rc;
+        if (int rc = slam_cross_launch(ctx, rev_idx, rev_dist, M, N, o_idx, o_dist)) return rc;
+        if (!zc) SLAM_HIP(hipMemcpyAsync(hb + off_o, db + off_o, (uint64_t)N * 8, hipMemcpyDeviceToHost, ctx->stream));
+        SLAM_HIP(hipStreamSynchronize(ctx->stream));
+        const int32_t* ri = (const int32_t*)(hb + off_o);
+        const int32_t* rd = (const int32_t*)(hb + off_o + (uint64_t)N * 4);
+        int64_t c = 0;
+        for (int64_t n = 0; n < N; n++) {
+            if (ri[n] < 0) continue;
+            h_query_idx[c] = (int32_t)n;
+            h_train_idx[c] = ri[n];
+            h_distance[c] = (float)rd[n];
+            c++;
+        }
+        *h_count = c;
+        return SLAM_OK;
+    }
     int32_t* d_idx = (int32_t*)(io + off_i);
     int32_t* d_dist = (int32_t*)(io + off_d);
     if (int rc = slam_bf_knn2_u256(ctx, dq, N, dt, M, 0, d_idx, d_dist)) return rc;

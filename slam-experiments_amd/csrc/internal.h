@@ -60,6 +60,9 @@ int slam_io_arena(slam_ctx* ctx, uint64_t dev_bytes, uint64_t host_bytes, void**
 // the filter kernels of slam_bf_match_filter without the read-back (asynchronous on the ctx stream)
 int slam_filter_launch(slam_ctx* ctx, const int32_t* d_idx, const int32_t* d_dist, int64_t N, int mode, double param,
                        uint8_t* d_keep);
+// the crossCheck kernels of slam_bf_cross_check without the read-back (asynchronous on the ctx stream)
+int slam_cross_launch(slam_ctx* ctx, const int32_t* d_rev_idx, const int32_t* d_rev_dist, int64_t M, int64_t N,
+                      int32_t* d_out_idx, int32_t* d_out_dist);
 // event bracket around the dominant kernel when profiling is on
 int slam_prof_begin(slam_ctx* ctx);
 int slam_prof_end(slam_ctx* ctx);

@@ -18,7 +18,7 @@ from .device import Context, DeviceBuffer, default_context
 
 NORM_HAMMING = 6           # cv2.NORM_HAMMING, the only norm the reference constructs (slam.py:24)
 IMGIDX_SHIFT = 18          # OpenCV's per-image row limit for multi-image train sets
-MODE_ALL, MODE_MIN_DIST, MODE_RATIO = 0, 1, 2
+MODE_ALL, MODE_MIN_DIST, MODE_RATIO, MODE_CROSS = 0, 1, 2, 3
 
 
 def as_descriptors(a) -> np.ndarray:
@@ -150,30 +150,11 @@ def ratio_test_arrays(query, train, ratio: float = 0.75, ctx: Optional[Context] 
 
 
 def cross_check_arrays(query, train, ctx: Optional[Context] = None):
-    """``cv2.BFMatcher(NORM_HAMMING, crossCheck=True).match(query, train)`` as arrays."""
+    """``cv2.BFMatcher(NORM_HAMMING, crossCheck=True).match(query, train)`` as arrays: one library call
+    (reverse search + selection on the device, ``slam_bf_match_host`` mode 3)."""
     q, t = as_descriptors(query), as_descriptors(train)
     ctx = ctx or default_context()
-    n, m = q.shape[0], t.shape[0]
-    if n == 0 or m == 0:
-        return np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0, np.float32)
-    dq, dt = DeviceDescriptors(ctx, q), DeviceDescriptors(ctx, t)
-    rev = Top2Table(ctx, m)
-    oi, od = ctx.malloc(n * 4), ctx.malloc(n * 4)
-    cnt = ctypes.c_int64(0)
-    try:
-        knn2_device(ctx, dt.buf, m, dq.buf, n, rev.idx, rev.dist)   # reverse search: train rows as queries
-        check(ctx.lib.slam_bf_cross_check(ctx.handle, rev.idx.ptr, rev.dist.ptr, m, n, oi.ptr, od.ptr,
-                                          ctypes.byref(cnt)))
-        idx = oi.download(np.int32, (n,))
-        dist = od.download(np.int32, (n,))
-    finally:
-        for b in (oi, od):
-            b.free()
-        rev.free()
-        dq.free()
-        dt.free()
-    keep = idx >= 0
-    return np.nonzero(keep)[0].astype(np.int32), idx[keep], dist[keep].astype(np.float32)
+    return _match_host(ctx, q, t, None, t.shape[0], None, MODE_CROSS, 0.0)
 
 
 def split_image_index(global_idx: np.ndarray, image_rows: Sequence[int]) -> Tuple[np.ndarray, np.ndarray]:

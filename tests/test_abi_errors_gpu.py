@@ -69,7 +69,7 @@ def test_host_buffer_entry_points(gpu_ctx):
     # both a host and a device train pointer, a bad mode, a missing count pointer, missing train rows
     assert lib.slam_bf_match_host(ctx.handle, q.ctypes.data, 37, t.ctypes.data, dt.ptr, 53, None, 0, 0.0, *args) == -1
     assert b"not both" in lib.slam_last_error()
-    assert lib.slam_bf_match_host(ctx.handle, q.ctypes.data, 37, t.ctypes.data, None, 53, None, 3, 0.0, *args) == -1
+    assert lib.slam_bf_match_host(ctx.handle, q.ctypes.data, 37, t.ctypes.data, None, 53, None, 4, 0.0, *args) == -1
     assert lib.slam_bf_match_host(ctx.handle, q.ctypes.data, 37, t.ctypes.data, None, 53, None, 0, 0.0, *args[:3], None) == -1
     assert lib.slam_bf_match_host(ctx.handle, q.ctypes.data, 37, None, None, 53, None, 0, 0.0, *args) == -1
     # empty sides: no matches, not an error
@@ -144,3 +144,27 @@ def test_host_calls_from_two_threads_share_a_context(gpu_ctx):
     for th in threads:
         th.join()
     assert not errors, errors[:3]
+
+
+@pytest.mark.parametrize("n,m", [(37, 53), (300, 120), (5000, 4500), (1, 9), (64, 1)])
+def test_cross_check_in_one_call(gpu_ctx, n, m):
+    """slam_bf_match_host mode 3 (crossCheck) against the oracle's one-pass OpenCV rule, host and device train."""
+    from oracle import oracle
+
+    lib, ctx = gpu_ctx.lib, gpu_ctx
+    rng = np.random.default_rng(n + 7 * m)
+    q = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    t = rng.integers(0, 256, (m, 32), dtype=np.uint8)
+    t[: min(m, n) // 2] = q[: min(m, n) // 2]                    # mutual nearest neighbours exist
+    oi, od = oracle.bf_cross_check_c(q, t)
+    eq, et, ed = np.flatnonzero(oi >= 0), oi[oi >= 0], od[oi >= 0]
+    qi, ti, di = np.empty(n, np.int32), np.empty(n, np.int32), np.empty(n, np.float32)
+    cnt = ctypes.c_int64(-1)
+    dt = ctx.upload(t)
+    for h_train, d_train in ((t.ctypes.data, None), (None, dt.ptr)):
+        assert lib.slam_bf_match_host(ctx.handle, q.ctypes.data, n, h_train, d_train, m, None, 3, 0.0, qi.ctypes.data,
+                                      ti.ctypes.data, di.ctypes.data, ctypes.byref(cnt)) == 0
+        c = cnt.value
+        assert c == len(eq) and np.array_equal(qi[:c], eq) and np.array_equal(ti[:c], et)
+        assert np.array_equal(di[:c], np.asarray(ed, np.float32))
+    dt.free()
