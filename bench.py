@@ -93,7 +93,30 @@ def cpu_baseline(query: np.ndarray, train: np.ndarray) -> dict:
                       f"(gcc -O3, {oracle.bf_simd()}, OpenMP {cores} threads), best of 3 = {dt:.2f} s wall; cv2 is not installed on this host"}
 
 
-def reproj_bench(ctx, steps: int, warmup: int) -> dict:
+def reproj_cpu_baseline(poses, points, obs_pose, obs_point, meas, intr) -> dict:
+    """Oracle (f64 C loop restating frontend.py:272-291) on all 1e7 observations, all cores and one thread."""
+    from oracle import oracle
+
+    cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
+    n = obs_pose.shape[0]
+    sl = slice(0, n)
+    args = (poses, points, obs_pose[sl], obs_point[sl], meas[sl], *intr)
+    out = oracle.reproj_rj_c(*args, with_point=True, threads=cores)     # page in; the output arrays are reused below
+    best = {}
+    for threads in (cores, 1):
+        dt = float("inf")
+        for _ in range(3):
+            t0 = time.perf_counter()
+            oracle.reproj_rj_c(*args, with_point=True, threads=threads, out=out)
+            dt = min(dt, time.perf_counter() - t0)
+        best[threads] = dt
+    return {"value": n / best[cores], "unit": "observations/s", "cores": cores, "kind": "port",
+            "single_thread": {"value": n / best[1], "unit": "observations/s"},
+            "sample": f"all {n} observations (the same arrays), oracle/reproj_oracle.c (gcc -O3, OpenMP {cores} threads), "
+                      f"best of 3 = {best[cores]:.3f} s ({best[1]:.3f} s on one thread) into preallocated outputs"}
+
+
+def reproj_bench(ctx, steps: int, warmup: int, cpu: bool = True) -> dict:
     """BASELINE configs[4]: 200 keyframes x 50k landmarks, dense 1e7 observations, residual + both Jacobians."""
     import slamhip
 
@@ -128,11 +151,15 @@ def reproj_bench(ctx, steps: int, warmup: int) -> dict:
     bytes_per_obs = 4 + 4 + 16 + 16 + 96 + 48           # two indices + pixel read; e, J_pose, J_point written
     kernel_ms = kms / max(launches, 1)
     gbs = O * bytes_per_obs / (kernel_ms * 1e-3) / 1e9
-    return {"workload": "200 poses x 50000 points dense = 1e7 observations, e + J_pose(2x6) + J_point(2x3), f64",
-            "observations_per_s": O / (ms * 1e-3), "ms_per_step": ms, "kernel_ms": kernel_ms,
-            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": gbs / HBM_PEAK_GBS, "traffic": profiled_traffic("reproj_rj_kernel"),
-                         "bytes_per_observation": bytes_per_obs}}
+    out = {"workload": "200 poses x 50000 points dense = 1e7 observations, e + J_pose(2x6) + J_point(2x3), f64",
+           "observations_per_s": O / (ms * 1e-3), "ms_per_step": ms, "kernel_ms": kernel_ms,
+           "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": gbs / HBM_PEAK_GBS, "traffic": profiled_traffic("reproj_rj_kernel"),
+                        "bytes_per_observation": bytes_per_obs}}
+    if cpu:
+        out["cpu_baseline"] = reproj_cpu_baseline(poses, points, obs_pose, obs_point, meas,
+                                                  (458.654, 457.296, 367.215, 248.375))
+    return out
 
 
 def main() -> int:
@@ -296,7 +323,7 @@ def main() -> int:
             out["cpu_baseline"] = None   # timed at N=1 only
     sm.free()
     if rank == 0 and world == 1 and not args.no_reproj:
-        out["reproj"] = reproj_bench(ctx, max(3, min(args.steps, 20)), 2)
+        out["reproj"] = reproj_bench(ctx, max(3, min(args.steps, 20)), 2, cpu=not args.no_cpu_baseline)
     if world > 1:
         check_rc = ctx.lib.slam_comm_destroy(ctx.handle) if collective == "rccl" else 0
         dist.barrier()

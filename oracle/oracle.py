@@ -218,16 +218,20 @@ def poses_to_rt12(T: np.ndarray) -> np.ndarray:
     return np.ascontiguousarray(T[:, :3, :4].reshape(T.shape[0], 12))
 
 
-def reproj_rj_c(poses12, points, obs_pose, obs_point, meas, fx, fy, cx, cy, with_point=True, threads=1):
+def reproj_rj_c(poses12, points, obs_pose, obs_point, meas, fx, fy, cx, cy, with_point=True, threads=1, out=None):
     poses12 = np.ascontiguousarray(poses12, np.float64)
     points = np.ascontiguousarray(points, np.float64)
     obs_pose = np.ascontiguousarray(obs_pose, np.int32)
     obs_point = np.ascontiguousarray(obs_point, np.int32)
     meas = np.ascontiguousarray(meas, np.float64)
     O = obs_pose.shape[0]
-    e = np.empty((O, 2))
-    Jp = np.empty((O, 2, 6))
-    Jq = np.empty((O, 2, 3)) if with_point else None
+    if out is not None:                                  # caller-owned output arrays (timing without page faults)
+        e, Jp, Jq = out
+        assert e.shape == (O, 2) and Jp.shape == (O, 2, 6) and (Jq is None or Jq.shape == (O, 2, 3))
+    else:
+        e = np.empty((O, 2))
+        Jp = np.empty((O, 2, 6))
+        Jq = np.empty((O, 2, 3)) if with_point else None
     rc = _load().oracle_reproj_rj_f64(_p(poses12), poses12.shape[0], _p(points), points.shape[0], _p(obs_pose),
                                       _p(obs_point), _p(meas), O, fx, fy, cx, cy, _p(e), _p(Jp), _p(Jq), threads)
     assert rc == 0
