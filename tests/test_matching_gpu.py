@@ -312,3 +312,36 @@ def test_host_call_path_boundaries(gpu_ctx, n, m):
     rq, rt, rd = slamhip.ratio_test_arrays(q, t, 0.75, ctx=gpu_ctx)
     assert np.array_equal(rq, np.flatnonzero(keep)) and np.array_equal(rt, ei[keep, 0])
     assert np.array_equal(rd, ed[keep, 0].astype(np.float32))
+
+
+def test_against_cv2_when_available(gpu_ctx):
+    """Confirmation against the real reference arithmetic (last row): runs only on a host where
+    opencv-python happens to be installed (it is absent from the build container and from the GPU image used in
+    round 1, where this test is skipped and parity stays 'unpinned')."""
+    cv2 = pytest.importorskip("cv2")
+    import slamhip
+
+    rng = np.random.default_rng(228)
+    t = rng.integers(0, 256, (700, 32), dtype=np.uint8)
+    q = rng.integers(0, 256, (500, 32), dtype=np.uint8)
+    q[:100] = t[:100]
+    q[:100, 3] ^= 0x05
+    t[650:] = t[600:650]                                          # duplicate train rows: tie order matters
+    knn = cv2.BFMatcher(cv2.NORM_HAMMING).knnMatch(q, t, k=2)
+    gi, gd = slamhip.knn_match_arrays(q, t, 2, ctx=gpu_ctx)
+    assert [[m.trainIdx for m in row] for row in knn] == gi.tolist()
+    assert [[int(m.distance) for m in row] for row in knn] == gd.tolist()
+    one = cv2.BFMatcher(cv2.NORM_HAMMING).match(q, t)
+    mq, mt, md = slamhip.match_arrays(t, q, None, ctx=gpu_ctx)
+    assert [m.queryIdx for m in one] == mq.tolist() and [m.trainIdx for m in one] == mt.tolist()
+    assert [m.distance for m in one] == md.tolist()
+    cross = cv2.BFMatcher(cv2.NORM_HAMMING, crossCheck=True).match(q, t)
+    cq, ct, cd = slamhip.cross_check_arrays(q, t, ctx=gpu_ctx)
+    assert [(m.queryIdx, m.trainIdx, m.distance) for m in cross] == list(zip(cq.tolist(), ct.tolist(), cd.tolist()))
+    bf = cv2.BFMatcher(cv2.NORM_HAMMING)
+    imgs = [t[:300], t[300:450], t[450:]]
+    bf.add(imgs)
+    multi = bf.knnMatch(q, k=2)
+    img, loc, dist = slamhip.knn_match_collection(q, imgs, 2, ctx=gpu_ctx)
+    assert [[(m.imgIdx, m.trainIdx, int(m.distance)) for m in row] for row in multi] == \
+        [[(int(img[i, k]), int(loc[i, k]), int(dist[i, k])) for k in range(2)] for i in range(len(q))]
