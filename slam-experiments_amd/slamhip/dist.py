@@ -48,12 +48,19 @@ class ShardPlan:
 
 def init_comm(ctx: Context, rank: int, world: int, bcast: Callable[[Optional[bytes]], bytes]) -> None:
     """Create the RCCL communicator of ``ctx``; ``bcast`` ships rank 0's unique id to everybody."""
-    ident = None
+    ident, failure = b"", None
     if rank == 0:
-        buf = ctypes.create_string_buffer(COMM_ID_BYTES)
-        check(ctx.lib.slam_comm_unique_id(buf))
-        ident = buf.raw
+        try:
+            buf = ctypes.create_string_buffer(COMM_ID_BYTES)
+            check(ctx.lib.slam_comm_unique_id(buf))
+            ident = buf.raw
+        except Exception as exc:   # noqa: BLE001 - the other ranks are waiting in bcast: tell them instead of hanging them
+            failure = exc
     ident = bcast(ident)
+    if failure is not None:
+        raise failure
+    if not ident:
+        raise RuntimeError("rank 0 could not create an RCCL unique id")
     if not isinstance(ident, (bytes, bytearray)) or len(ident) != COMM_ID_BYTES:
         raise ValueError("bcast must return the 128-byte id produced on rank 0")
     check(ctx.lib.slam_comm_init(ctx.handle, world, rank, ctypes.create_string_buffer(bytes(ident), COMM_ID_BYTES)))

@@ -196,3 +196,38 @@ def test_backend_container_glue_without_gpu(monkeypatch):
     assert fr.pose.T[0, 3] == 42.0 and fr.features[0].map_point is a and fr.features[2].map_point is None
     assert not fr.features[0].is_outlier and not fr.features[2].is_outlier and fr.features[1].is_outlier
     assert backend.Backend().correct_frame_pose(Frame(1, Pose(T(0))), 1.0, 1.0, 0.0, 0.0) == 0
+
+
+def test_init_comm_failure_reaches_every_rank():
+    """If rank 0 cannot create the RCCL id it still takes part in the broadcast (an empty id), so the other
+    ranks raise instead of waiting forever; no GPU or library needed for this logic."""
+    from slamhip import dist as sdist
+    from slamhip._lib import SlamHipError
+
+    class Lib:
+        def __init__(self, rc): self.rc, self.inits = rc, 0
+        def slam_comm_unique_id(self, buf): return self.rc
+        def slam_comm_init(self, *a): self.inits += 1; return 0
+        def slam_last_error(self): return b"librccl.so not found"
+
+    class Ctx:
+        def __init__(self, rc): self.lib, self.handle = Lib(rc), None
+
+    sent = []
+    bad = Ctx(-4)
+    import slamhip._lib as L
+    old = L._lib
+    L._lib = bad.lib                                     # check() reads the message from the loaded library
+    try:
+        with pytest.raises(SlamHipError):
+            sdist.init_comm(bad, 0, 2, lambda ident: sent.append(ident) or ident)
+        assert sent == [b""] and bad.lib.inits == 0      # the broadcast still happened, with the empty id
+        other = Ctx(0)
+        with pytest.raises(RuntimeError):
+            sdist.init_comm(other, 1, 2, lambda ident: sent[0])
+        assert other.lib.inits == 0
+        ok = Ctx(0)
+        sdist.init_comm(ok, 0, 1, lambda ident: ident)   # healthy path: 128-byte id goes round, communicator created
+        assert ok.lib.inits == 1
+    finally:
+        L._lib = old
