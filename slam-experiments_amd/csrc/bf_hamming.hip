@@ -394,7 +394,7 @@ static void plan_for(const slam_ctx* ctx, int64_t N, int64_t M, int R, int block
 static bf_plan make_plan(const slam_ctx* ctx, int64_t N, int64_t M) {
     bf_plan p;
     // R = 1 query per lane measured fastest at every size tried (64k x 64k: 1.68 ms vs 1.79 ms for R = 2,
-    // 1.96 ms for R = 4; 54 VGPRs, 8 waves/SIMD); R = 2 / 4 / 8 stay available through slam_bf_set_tuning.
+    // 1.96 ms for R = 4; 58 VGPRs, 8 waves/SIMD); R = 2 / 4 / 8 stay available through slam_bf_set_tuning.
     plan_for(ctx, N, M, g_force_R ? g_force_R : 1, g_blocks_per_cu, &p);
     return p;
 }
