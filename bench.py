@@ -204,37 +204,53 @@ def main() -> int:
     ctx = slamhip.Context(0 if os.environ.get("SLAM_BENCH_SINGLE_DEVICE") == "1" else local_rank)
     query, train = make_descriptors(N_QUERY, 228), make_descriptors(N_TRAIN, 229)
 
+    def barrier():
+        ctx.sync()
+        if dist is not None:
+            dist.barrier()
+
+    collective = "none"
+    rccl_ok = False
     if world > 1:
+        import torch
+
         def bcast(ident):
             box = [ident]
             dist.broadcast_object_list(box, src=0)
             return box[0]
 
-        # RCCL is the data path.  If its communicator cannot be created on this node, say so loudly and gather
-        # through the host (gloo) instead, so that a scaling number - labelled as such - still exists.
-        collective = "rccl"
+        def allgather_obj(x):
+            out = [None] * world
+            dist.all_gather_object(out, x)
+            return out
+
+        # RCCL is the data path.  If its communicator cannot be created on this node, say so loudly and use the
+        # library's own direct all-gather over xGMI peer mappings (HIP IPC); if that cannot be set up either,
+        # gather through the host (gloo), so that a scaling number - labelled as such - still exists.
+        force = os.environ.get("SLAM_BENCH_COLLECTIVE", "")    # test hook: "p2p" / "gloo" skip the tiers above them
         try:
+            if force in ("p2p", "gloo"):
+                raise RuntimeError(f"skipped: SLAM_BENCH_COLLECTIVE={force}")
             init_comm(ctx, rank, world, bcast)
             failed = 0
         except Exception as exc:   # noqa: BLE001 - any failure of the native init
-            print(f"[bench] rank {rank}: RCCL communicator init failed ({exc}); falling back to a host gather", file=sys.stderr)
+            print(f"[bench] rank {rank}: RCCL communicator init failed ({exc}); trying peer copies over HIP IPC", file=sys.stderr)
             failed = 1
-        import torch
-
         flag = torch.tensor([failed])
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-        if int(flag[0]):
-            collective = "gloo-host-fallback"
+        rccl_ok = not int(flag[0])
+        if not rccl_ok:
             ctx.lib.slam_comm_destroy(ctx.handle)
-    else:
-        collective = "none"
 
-    sm = ShardedMatcher(ctx, rank, world, query, train)
-    if collective == "gloo-host-fallback":
-        import torch
-
+    sm = ShardedMatcher(ctx, rank, world, query, train, collective="rccl" if rccl_ok else None)
+    if world > 1 and rccl_ok:
+        collective = "rccl"
+    elif world > 1 and os.environ.get("SLAM_BENCH_COLLECTIVE") != "gloo" and sm.enable_p2p(allgather_obj, barrier):
+        collective = "xgmi-p2p-copies"
+    elif world > 1:
+        collective = "gloo-host-fallback"
+        print(f"[bench] rank {rank}: peer mapping failed too ({getattr(sm, 'p2p_error', 'marker check')}); gathering through the host", file=sys.stderr)
         device_step = sm.step
-        sm.world = 1                                   # no native collective inside step()
 
         def host_gather_step():
             device_step()
@@ -244,11 +260,6 @@ def main() -> int:
             sm.host_table = torch.cat(parts).numpy()
 
         sm.step = host_gather_step
-
-    def barrier():
-        ctx.sync()
-        if dist is not None:
-            dist.barrier()
 
     # device spin-up, not part of the measurement: the GPU needs ~10 passes (~20 ms) of load before DVFS
     # reaches its steady clock (tools/ramp.py: 3.0, 2.1, 2.0 ... 1.76 ms per pass from idle)

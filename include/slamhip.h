@@ -244,6 +244,21 @@ SLAM_API int slam_comm_allgather_overlapped(slam_ctx* ctx, const void* d_send, v
                                             int buffer_id);
 SLAM_API int slam_comm_wait_buffer(slam_ctx* ctx, int buffer_id);
 
+/* ---- multi-GPU without a communicator library: direct all-gather over xGMI peer mappings (HIP IPC) ----
+ * Each rank exports its gathered buffer(s) (slam_p2p_export on the base pointer of a slam_malloc allocation),
+ * the launcher ships the 64-byte handles around, every rank maps the peers' buffers (slam_p2p_open) and
+ * slam_p2p_allgather_overlapped then copies this rank's slot (bytes_per_rank at offset rank*bytes_per_rank) into
+ * every peer's buffer on the context's second stream, behind the work queued so far on the main stream.
+ * h_peer_bufs is a HOST array of nranks device pointers (entry [rank] unused).  slam_comm_wait_buffer(buffer_id)
+ * orders later main-stream work after these copies; arrival on the peers is the launcher's barrier to guarantee.
+ * No reference counterpart (the reference is single-process). */
+#define SLAM_P2P_HANDLE_BYTES 64
+SLAM_API int slam_p2p_export(slam_ctx* ctx, void* d_ptr, void* h_handle /*[64]*/);
+SLAM_API int slam_p2p_open(slam_ctx* ctx, const void* h_handle, void** d_peer_ptr);
+SLAM_API int slam_p2p_close(slam_ctx* ctx, void* d_peer_ptr);
+SLAM_API int slam_p2p_allgather_overlapped(slam_ctx* ctx, const void* d_send, uint64_t bytes_per_rank, int rank,
+                                           void* const* h_peer_bufs, int nranks, int buffer_id);
+
 #ifdef __cplusplus
 }
 #endif

@@ -77,13 +77,7 @@ extern "C" int slam_comm_init(slam_ctx* ctx, int nranks, int rank, const void* h
     ctx->comm = comm;
     ctx->comm_rank = rank;
     ctx->comm_nranks = nranks;
-    SLAM_HIP(hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
-    SLAM_HIP(hipEventCreateWithFlags(&ctx->comm_ready, hipEventDisableTiming));
-    for (int i = 0; i < 2; i++) {
-        SLAM_HIP(hipEventCreateWithFlags(&ctx->comm_done[i], hipEventDisableTiming));
-        ctx->comm_done_valid[i] = false;
-    }
-    return SLAM_OK;
+    return slam_second_stream(ctx);
 }
 
 extern "C" int slam_comm_destroy(slam_ctx* ctx) {
@@ -91,16 +85,7 @@ extern "C" int slam_comm_destroy(slam_ctx* ctx) {
     if (!ctx->comm) return SLAM_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    if (ctx->comm_stream) {
-        (void)hipStreamSynchronize(ctx->comm_stream);
-        (void)hipStreamDestroy(ctx->comm_stream);
-        ctx->comm_stream = nullptr;
-    }
-    if (ctx->comm_ready) { (void)hipEventDestroy(ctx->comm_ready); ctx->comm_ready = nullptr; }
-    for (int i = 0; i < 2; i++) {
-        if (ctx->comm_done[i]) { (void)hipEventDestroy(ctx->comm_done[i]); ctx->comm_done[i] = nullptr; }
-        ctx->comm_done_valid[i] = false;
-    }
+    slam_second_stream_destroy(ctx);
     ncclResult_t r = g_rccl.CommDestroy((ncclComm_t)ctx->comm);
     ctx->comm = nullptr;
     ctx->comm_rank = -1;
@@ -151,7 +136,7 @@ extern "C" int slam_comm_allgather_overlapped(slam_ctx* ctx, const void* d_send,
 extern "C" int slam_comm_wait_buffer(slam_ctx* ctx, int buffer_id) {
     SLAM_REQUIRE(ctx, "slam_comm_wait_buffer: null ctx");
     SLAM_REQUIRE(buffer_id == 0 || buffer_id == 1, "buffer_id must be 0 or 1");
-    if (!ctx->comm || !ctx->comm_done_valid[buffer_id]) return SLAM_OK;   // nothing in flight for this buffer
+    if (!ctx->comm_done_valid[buffer_id]) return SLAM_OK;   // nothing in flight for this buffer
     SLAM_HIP(hipSetDevice(ctx->device));
     SLAM_HIP(hipStreamWaitEvent(ctx->stream, ctx->comm_done[buffer_id], 0));
     return SLAM_OK;

@@ -65,6 +65,7 @@ extern "C" int slam_ctx_destroy(slam_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->comm) slam_comm_destroy(ctx);
+    slam_second_stream_destroy(ctx);
     for (auto& kv : ctx->allocs) (void)hipFree(kv.first);
     if (ctx->workspace) (void)hipFree(ctx->workspace);
     if (ctx->scratch) (void)hipFree(ctx->scratch);

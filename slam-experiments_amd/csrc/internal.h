@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdarg.h>
+#include <string.h>
 #include <unordered_map>
 #include <mutex>
 #include "slamhip.h"
@@ -63,6 +64,9 @@ int slam_filter_launch(slam_ctx* ctx, const int32_t* d_idx, const int32_t* d_dis
 // the crossCheck kernels of slam_bf_cross_check without the read-back (asynchronous on the ctx stream)
 int slam_cross_launch(slam_ctx* ctx, const int32_t* d_rev_idx, const int32_t* d_rev_dist, int64_t M, int64_t N,
                       int32_t* d_out_idx, int32_t* d_out_dist);
+// second stream + hand-off events shared by the RCCL and the peer-copy all-gathers (p2p.hip)
+int slam_second_stream(slam_ctx* ctx);
+void slam_second_stream_destroy(slam_ctx* ctx);
 // event bracket around the dominant kernel when profiling is on
 int slam_prof_begin(slam_ctx* ctx);
 int slam_prof_end(slam_ctx* ctx);

@@ -17,6 +17,7 @@ NO_MATCH_IDX = -1
 NO_MATCH_DIST = 2**31 - 1
 DESC_BYTES = 32
 COMM_ID_BYTES = 128
+P2P_HANDLE_BYTES = 64
 
 
 class SlamHipError(RuntimeError):
@@ -80,6 +81,10 @@ SIGNATURES = {
     "slam_comm_broadcast": (c_int, [c_void_p, c_void_p, c_uint64, c_int]),
     "slam_comm_allgather_overlapped": (c_int, [c_void_p, c_void_p, c_void_p, c_uint64, c_int]),
     "slam_comm_wait_buffer": (c_int, [c_void_p, c_int]),
+    "slam_p2p_export": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "slam_p2p_open": (c_int, [c_void_p, c_void_p, POINTER(c_void_p)]),
+    "slam_p2p_close": (c_int, [c_void_p, c_void_p]),
+    "slam_p2p_allgather_overlapped": (c_int, [c_void_p, c_void_p, c_uint64, c_int, c_void_p, c_int, c_int]),
 }
 
 _lib = None

@@ -19,7 +19,7 @@ from typing import Callable, Optional, Tuple
 
 import numpy as np
 
-from ._lib import COMM_ID_BYTES, DESC_BYTES, check
+from ._lib import COMM_ID_BYTES, DESC_BYTES, P2P_HANDLE_BYTES, check
 from .device import Context, DeviceBuffer
 from .matching import DeviceDescriptors, as_descriptors, knn2_device
 
@@ -66,11 +66,68 @@ def init_comm(ctx: Context, rank: int, world: int, bcast: Callable[[Optional[byt
     check(ctx.lib.slam_comm_init(ctx.handle, world, rank, ctypes.create_string_buffer(bytes(ident), COMM_ID_BYTES)))
 
 
-class ShardedMatcher:
-    """knn=2 search of a query set sharded over ``world`` GPUs against a replicated train set."""
+class PeerMap:
+    """The peers' gathered buffers mapped into this process through HIP IPC (``slam_p2p_*``): the direct
+    all-gather over xGMI used when no RCCL communicator can be created."""
 
-    def __init__(self, ctx: Context, rank: int, world: int, query, train):
+    def __init__(self, ctx: Context, rank: int, world: int, buffers, allgather_obj: Callable[[object], list]):
+        """``buffers``: this rank's gathered buffers (base allocations); ``allgather_obj(x) -> [x of rank 0, ...]``
+        is the launcher's object all-gather (e.g. ``torch.distributed.all_gather_object`` over gloo)."""
         self.ctx, self.rank, self.world = ctx, rank, world
+        self.ptrs, self.tables = [], []     # [buffer][rank] -> device pointer (0 for this rank); and as ctypes arrays
+        mine, failure = [], None
+        try:
+            for b in buffers:
+                h = ctypes.create_string_buffer(P2P_HANDLE_BYTES)
+                check(ctx.lib.slam_p2p_export(ctx.handle, b.ptr, h))
+                mine.append(h.raw)
+        except Exception as exc:   # noqa: BLE001 - still take part in the exchange below, or the peers would hang
+            mine, failure = None, exc
+        everyone = allgather_obj(mine)
+        if failure is not None:
+            raise failure
+        if any(x is None for x in everyone):
+            raise RuntimeError("a peer could not export its gathered buffers")
+        try:
+            for bi in range(len(buffers)):
+                row = []
+                self.ptrs.append(row)
+                for r in range(world):
+                    if r == rank:
+                        row.append(0)
+                        continue
+                    p = ctypes.c_void_p()
+                    check(ctx.lib.slam_p2p_open(ctx.handle, ctypes.create_string_buffer(everyone[r][bi], P2P_HANDLE_BYTES),
+                                                ctypes.byref(p)))
+                    row.append(p.value or 0)
+                self.tables.append((ctypes.c_void_p * world)(*row))
+        except Exception:
+            self.close()
+            raise
+
+    def push(self, send: DeviceBuffer, bytes_per_rank: int, buffer_id: int) -> None:
+        c = self.ctx
+        check(c.lib.slam_p2p_allgather_overlapped(c.handle, send.ptr, bytes_per_rank, self.rank, self.tables[buffer_id],
+                                                  self.world, buffer_id))
+
+    def close(self) -> None:
+        for row in self.ptrs:
+            for p in row:
+                if p:
+                    check(self.ctx.lib.slam_p2p_close(self.ctx.handle, p))
+        self.ptrs, self.tables = [], []
+
+
+class ShardedMatcher:
+    """knn=2 search of a query set sharded over ``world`` GPUs against a replicated train set.
+
+    ``collective``: "rccl" (communicator made by ``init_comm``), "p2p" (peer copies over HIP IPC, enabled with
+    ``enable_p2p``) or None (no gather: every rank keeps only its own slot)."""
+
+    def __init__(self, ctx: Context, rank: int, world: int, query, train, collective: Optional[str] = "rccl"):
+        self.ctx, self.rank, self.world = ctx, rank, world
+        self.collective = collective if world > 1 else None
+        self.peers: Optional[PeerMap] = None
         query, train = as_descriptors(query), as_descriptors(train)
         self.plan = ShardPlan(query.shape[0], world)
         self.n_train = train.shape[0]
@@ -101,16 +158,56 @@ class ShardedMatcher:
         """One pass: local search into this rank's slot, then the all-gather of that buffer (all asynchronous)."""
         ctx = self.ctx
         b = self.passes % len(self.gathered)
-        if self.world > 1:
+        if self.collective:
             check(ctx.lib.slam_comm_wait_buffer(ctx.handle, b))      # the gather that last used this buffer is done
         if self.n_local:
             knn2_device(ctx, self.d_query.buf, self.n_local, self.d_train.buf, self.n_train, self.my_idx[b],
                         self.my_dist[b])
-        if self.world > 1:
+        if self.collective == "rccl":
             check(ctx.lib.slam_comm_allgather_overlapped(ctx.handle, self.my_idx[b].ptr, self.gathered[b].ptr,
                                                          self.slot_bytes, b))
+        elif self.collective == "p2p":
+            self.peers.push(self.my_idx[b], self.slot_bytes, b)
         self.last = b
         self.passes += 1
+
+    def enable_p2p(self, allgather_obj: Callable[[object], list], barrier: Callable[[], None]) -> bool:
+        """Map the peers' gathered buffers and prove the mapping with a round of marker writes; True on every rank
+        or False on every rank (``allgather_obj`` carries the verdicts).  On success ``collective`` becomes "p2p";
+        ``result()`` is then only complete after the launcher's barrier (all ranks synced, then a process barrier)."""
+        ok = True
+        try:
+            self.peers = PeerMap(self.ctx, self.rank, self.world, self.gathered, allgather_obj)
+        except Exception as exc:   # noqa: BLE001 - any rank may fail to map; the verdict is agreed below
+            self.peers, ok = None, False
+            self.p2p_error = str(exc)
+        verdicts = allgather_obj(ok)
+        if not all(verdicts):
+            if self.peers is not None:
+                self.peers.close()
+                self.peers = None
+            return False
+        # marker round: every rank writes rank+1 into the first bytes of its slot everywhere, then checks all slots
+        mark = np.full(16, self.rank + 1, np.uint8)
+        for b, g in enumerate(self.gathered):
+            self.my_idx[b].upload(mark)
+            self.peers.push(self.my_idx[b], self.slot_bytes, b)    # the whole slot: the offset is rank * slot_bytes
+        barrier()
+        good = True
+        for g in self.gathered:
+            raw = g.download(np.uint8, (self.world, self.slot_bytes))
+            good = good and all((raw[r, :16] == r + 1).all() for r in range(self.world))
+        for g in self.gathered:                                  # back to "no match" everywhere before real passes
+            check(self.ctx.lib.slam_memset(self.ctx.handle, g.ptr, 0xFF, g.nbytes))
+        self.ctx.sync()
+        verdicts = allgather_obj(bool(good))
+        barrier()
+        if not all(verdicts):
+            self.peers.close()
+            self.peers = None
+            return False
+        self.collective = "p2p"
+        return True
 
     def result(self) -> Tuple[np.ndarray, np.ndarray]:
         """The complete [N,2] tables of the most recent pass (waits for both streams)."""
@@ -125,6 +222,9 @@ class ShardedMatcher:
 
     def free(self) -> None:
         self.ctx.sync()
+        if self.peers is not None:
+            self.peers.close()
+            self.peers = None
         for g in self.gathered:
             g.free()
         self.d_query.free()

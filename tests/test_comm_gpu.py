@@ -61,16 +61,19 @@ def test_bench_under_the_driver_launcher_one_rank(built):
     assert rec["roofline"]["kernel_ms"] > 0 and rec["unit"] == "pairs/s"
 
 
-def test_two_ranks_on_one_gpu_take_the_loud_fallback(built):
+@pytest.mark.parametrize("force,expect", [("", ("rccl", "xgmi-p2p-copies")), ("gloo", ("gloo-host-fallback",))])
+def test_two_ranks_on_one_gpu_take_the_loud_fallbacks(built, force, expect):
     """Two ranks sharing GPU 0: RCCL refuses duplicate devices, so this exercises the rendezvous, the failure
-    handling and the host-gather fallback of bench.py end to end (sharded result == oracle spot check)."""
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", SLAM_BENCH_SINGLE_DEVICE="1")
+    handling and the next tiers of bench.py end to end - the peer-copy all-gather through HIP IPC mappings (a real
+    device-to-device gather between two processes), and with SLAM_BENCH_COLLECTIVE=gloo the host gather below it.
+    Either way the sharded result must equal the oracle spot check."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", SLAM_BENCH_SINGLE_DEVICE="1", SLAM_BENCH_COLLECTIVE=force)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", "29633", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
-           "--warmup", "1"]
+           "127.0.0.1", "--master-port", "29633" if force else "29635", os.path.join(ROOT, "bench.py"), "--gpus", "2",
+           "--steps", "3", "--warmup", "1"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
     rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert rec["n_gpus"] == 2 and rec["parity_spot_check"] is True
-    assert rec["config"]["collective"] in ("rccl", "gloo-host-fallback")
+    assert rec["config"]["collective"] in expect, (rec["config"]["collective"], out.stderr[-2000:])
     assert rec["cpu_baseline"] is None
