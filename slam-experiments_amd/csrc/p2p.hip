@@ -85,7 +85,7 @@ extern "C" int slam_p2p_allgather_overlapped(slam_ctx* ctx, const void* d_send, 
             const int p = (rank + step) % nranks;          // staggered: at any moment the ranks target different peers
             SLAM_REQUIRE(h_peer_bufs[p], "slam_p2p_allgather_overlapped: peer %d is not mapped", p);
             char* dst = (char*)h_peer_bufs[p] + (uint64_t)rank * bytes_per_rank;
-            SLAM_HIP(hipMemcpyAsync(dst, d_send, bytes_per_rank, hipMemcpyDeviceToDevice, ctx->comm_stream));
+            SLAM_HIP(hipMemcpyAsync(dst, d_send, bytes_per_rank, hipMemcpyDefault, ctx->comm_stream));   // kind inferred: the target may live on another GPU
         }
     }
     SLAM_HIP(hipEventRecord(ctx->comm_done[buffer_id], ctx->comm_stream));
