@@ -231,3 +231,57 @@ def test_init_comm_failure_reaches_every_rank():
         assert ok.lib.inits == 1
     finally:
         L._lib = old
+
+
+def test_peer_map_failure_reaches_every_rank():
+    """PeerMap: a rank that cannot export its buffers still takes part in the handle exchange (with None), so its
+    peers raise instead of hanging; opened mappings are closed again when a later open fails."""
+    from slamhip import dist as sdist
+    from slamhip._lib import SlamHipError
+    import slamhip._lib as L
+
+    class Lib:
+        def __init__(self, export_rc=0, fail_open_at=None):
+            self.export_rc, self.fail_open_at, self.opened, self.closed = export_rc, fail_open_at, 0, 0
+        def slam_p2p_export(self, h, ptr, buf): return self.export_rc
+        def slam_p2p_open(self, h, handle, out):
+            if self.fail_open_at is not None and self.opened == self.fail_open_at:
+                return -2
+            self.opened += 1
+            out._obj.value = 0x1000 * self.opened
+            return 0
+        def slam_p2p_close(self, h, p): self.closed += 1; return 0
+        def slam_last_error(self): return b"hipIpcGetMemHandle failed"
+
+    class Ctx:
+        def __init__(self, lib): self.lib, self.handle = lib, None
+
+    class Buf:
+        ptr = 0x5000
+
+    calls = []
+    old = L._lib
+    try:
+        bad = Lib(export_rc=-2)
+        L._lib = bad
+        with pytest.raises(SlamHipError):
+            sdist.PeerMap(Ctx(bad), 0, 2, [Buf(), Buf()], lambda x: calls.append(x) or [x, [b"h" * 64] * 2])
+        assert calls == [None]                                   # the exchange still happened
+        peer = Lib()
+        L._lib = peer
+        with pytest.raises(RuntimeError):
+            sdist.PeerMap(Ctx(peer), 1, 2, [Buf(), Buf()], lambda x: [None, x])
+        assert peer.opened == 0
+        flaky = Lib(fail_open_at=1)                              # second mapping fails: the first one is closed again
+        L._lib = flaky
+        with pytest.raises(SlamHipError):
+            sdist.PeerMap(Ctx(flaky), 0, 2, [Buf(), Buf()], lambda x: [x, [b"h" * 64] * 2])
+        assert flaky.opened == 1 and flaky.closed == 1
+        good = Lib()
+        L._lib = good
+        pm = sdist.PeerMap(Ctx(good), 0, 3, [Buf(), Buf()], lambda x: [x, [b"h" * 64] * 2, [b"g" * 64] * 2])
+        assert good.opened == 4 and [len(r) for r in pm.ptrs] == [3, 3] and pm.ptrs[0][0] == 0
+        pm.close()
+        assert good.closed == 4
+    finally:
+        L._lib = old
