@@ -77,6 +77,7 @@ SLAM_API int slam_sync(slam_ctx* ctx);
 SLAM_API int slam_malloc(slam_ctx* ctx, uint64_t bytes, void** d_ptr);
 SLAM_API int slam_free(slam_ctx* ctx, void* d_ptr);
 SLAM_API int slam_memset(slam_ctx* ctx, void* d_ptr, int value, uint64_t bytes);
+SLAM_API int slam_copy(slam_ctx* ctx, void* d_dst, const void* d_src, uint64_t bytes); /* device to device, asynchronous on the ctx stream */
 SLAM_API int slam_upload(slam_ctx* ctx, void* d_dst, const void* h_src, uint64_t bytes);
 SLAM_API int slam_download(slam_ctx* ctx, void* h_dst, const void* d_src, uint64_t bytes);
 

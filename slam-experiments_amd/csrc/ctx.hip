@@ -132,6 +132,14 @@ extern "C" int slam_memset(slam_ctx* ctx, void* d_ptr, int value, uint64_t bytes
     return SLAM_OK;
 }
 
+extern "C" int slam_copy(slam_ctx* ctx, void* d_dst, const void* d_src, uint64_t bytes) {
+    SLAM_REQUIRE(ctx && ((d_dst && d_src) || !bytes), "slam_copy: null argument");
+    if (!bytes) return SLAM_OK;
+    SLAM_HIP(hipSetDevice(ctx->device));
+    SLAM_HIP(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return SLAM_OK;
+}
+
 extern "C" int slam_upload(slam_ctx* ctx, void* d_dst, const void* h_src, uint64_t bytes) {
     SLAM_REQUIRE(ctx && ((d_dst && h_src) || !bytes), "slam_upload: null argument");
     if (!bytes) return SLAM_OK;

@@ -5,6 +5,7 @@ from .device import Context, DeviceBuffer, default_context  # noqa: F401
 from .matching import (  # noqa: F401
     NORM_HAMMING,
     DeviceDescriptors,
+    KeyframeDatabase,
     ResidentMatcher,
     Top2Table,
     as_descriptors,

@@ -40,6 +40,7 @@ SIGNATURES = {
     "slam_malloc": (c_int, [c_void_p, c_uint64, POINTER(c_void_p)]),
     "slam_free": (c_int, [c_void_p, c_void_p]),
     "slam_memset": (c_int, [c_void_p, c_void_p, c_int, c_uint64]),
+    "slam_copy": (c_int, [c_void_p, c_void_p, c_void_p, c_uint64]),
     "slam_upload": (c_int, [c_void_p, c_void_p, c_void_p, c_uint64]),
     "slam_download": (c_int, [c_void_p, c_void_p, c_void_p, c_uint64]),
     "slam_timer_start": (c_int, [c_void_p]),

@@ -216,3 +216,64 @@ class ResidentMatcher:
             if prev is not None:
                 prev.free()
         return None if prev is None else out
+
+
+class KeyframeDatabase:
+    """Loop-closure layout kept in HBM (BASELINE.json configs[3]): the descriptors of every keyframe added so far
+    live in one growing device buffer, and a query frame is searched against all of them in one launch.
+
+    The result has OpenCV's multi-image form (``BFMatcher.add`` + ``knnMatch``): per query and neighbour the
+    keyframe (``imgIdx``), the row inside it (``trainIdx``) and the distance, ordered by (distance, imgIdx, trainIdx).
+    Only the new keyframe's rows cross PCIe on ``add``; queries upload the query rows and download the [N,k] tables."""
+
+    def __init__(self, ctx: Optional[Context] = None, capacity_rows: int = 1 << 16):
+        self.ctx = ctx or default_context()
+        self._cap = max(int(capacity_rows), 1)
+        self._buf = self.ctx.malloc(self._cap * DESC_BYTES)
+        self.rows: list = []            # rows per keyframe, in insertion order
+        self.total = 0
+
+    def add(self, descriptors) -> int:
+        """Append one keyframe's descriptors; returns its index (the ``imgIdx`` later results refer to)."""
+        d = as_descriptors(descriptors)
+        n = d.shape[0]
+        if n >= (1 << IMGIDX_SHIFT):
+            raise ValueError("a keyframe must have fewer than 2^18 rows (OpenCV IMGIDX_ONE)")
+        if self.total + n > self._cap:
+            cap = self._cap
+            while cap < self.total + n:
+                cap *= 2
+            grown = self.ctx.malloc(cap * DESC_BYTES)
+            if self.total:                                   # device-to-device through the library's copy primitive
+                check(self.ctx.lib.slam_copy(self.ctx.handle, grown.ptr, self._buf.ptr, self.total * DESC_BYTES))
+            self._buf.free()
+            self._buf, self._cap = grown, cap
+        if n:
+            self._buf.view(self.total * DESC_BYTES, n * DESC_BYTES).upload(d)
+        self.rows.append(n)
+        self.total += n
+        return len(self.rows) - 1
+
+    def query(self, descriptors, k: int = 2):
+        """(imgIdx, trainIdx, dist) int32 [N,k] of the query rows against every keyframe added so far."""
+        if k not in (1, 2):
+            raise ValueError("k must be 1 or 2")
+        q = as_descriptors(descriptors)
+        n = q.shape[0]
+        if n == 0:
+            z = np.zeros((0, k), np.int32)
+            return z, z.copy(), z.copy()
+        dq = DeviceDescriptors(self.ctx, q)
+        table = Top2Table(self.ctx, n)
+        try:
+            knn2_device(self.ctx, dq.buf, n, self._buf, self.total, table.idx, table.dist)
+            idx, dist = table.download()
+        finally:
+            table.free()
+            dq.free()
+        img, local = split_image_index(idx, self.rows)
+        return (np.ascontiguousarray(img[:, :k]), np.ascontiguousarray(local[:, :k]), np.ascontiguousarray(dist[:, :k]))
+
+    def free(self) -> None:
+        self._buf.free()
+        self.rows, self.total = [], 0

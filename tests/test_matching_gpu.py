@@ -345,3 +345,32 @@ def test_against_cv2_when_available(gpu_ctx):
     img, loc, dist = slamhip.knn_match_collection(q, imgs, 2, ctx=gpu_ctx)
     assert [[(m.imgIdx, m.trainIdx, int(m.distance)) for m in row] for row in multi] == \
         [[(int(img[i, k]), int(loc[i, k]), int(dist[i, k])) for k in range(2)] for i in range(len(q))]
+
+
+def test_keyframe_database_matches_collection_semantics(gpu_ctx):
+    """KeyframeDatabase (descriptors of all keyframes resident in HBM, growing) == knnMatch against the same
+    images as a collection (oracle: OpenCV's imgIdx<<18|trainIdx order), across a capacity growth and with an
+    empty keyframe in between."""
+    import slamhip
+    from oracle import oracle
+
+    rng = np.random.default_rng(314)
+    db = slamhip.KeyframeDatabase(gpu_ctx, capacity_rows=256)
+    imgs = []
+    for rows in (200, 0, 300, 1000, 37):
+        kf = rng.integers(0, 256, (rows, 32), dtype=np.uint8)
+        if rows and imgs and imgs[0].shape[0]:
+            kf[: min(rows, 20)] = imgs[0][: min(rows, 20)]        # repeated places: ties across keyframes
+        assert db.add(kf) == len(imgs)
+        imgs.append(kf)
+        q = rng.integers(0, 256, (150, 32), dtype=np.uint8)
+        q[:20] = imgs[0][:20]
+        img, loc, dist = db.query(q, 2)
+        ei, el, ed = oracle.bf_knn_multi_c(q, imgs, 2)
+        assert np.array_equal(img, ei) and np.array_equal(loc, el) and np.array_equal(dist, ed)
+    assert db.total == 1537 and db.rows == [200, 0, 300, 1000, 37]
+    i1, l1, d1 = db.query(q, 1)
+    assert np.array_equal(i1, ei[:, :1]) and np.array_equal(l1, el[:, :1]) and np.array_equal(d1, ed[:, :1])
+    e = db.query(np.zeros((0, 32), np.uint8), 2)
+    assert all(a.shape == (0, 2) for a in e)
+    db.free()
