@@ -118,7 +118,60 @@ class PeerMap:
         self.ptrs, self.tables = [], []
 
 
-class ShardedMatcher:
+class _Gathering:
+    """What both sharded matchers share: gathered buffers with one slot per rank, and the peer-copy tier.
+    Subclasses set ``ctx, rank, world, gathered`` (device buffers), ``_slots`` (this rank's slot in each of them),
+    ``slot_bytes``, ``collective`` and ``peers``."""
+
+    def _gather(self, b: int) -> None:
+        """All-gather this rank's slot of gathered buffer ``b`` (asynchronous, second stream)."""
+        ctx = self.ctx
+        if self.collective == "rccl":
+            check(ctx.lib.slam_comm_allgather_overlapped(ctx.handle, self._slots[b].ptr, self.gathered[b].ptr,
+                                                         self.slot_bytes, b))
+        elif self.collective == "p2p":
+            self.peers.push(self._slots[b], self.slot_bytes, b)
+
+    def enable_p2p(self, allgather_obj: Callable[[object], list], barrier: Callable[[], None]) -> bool:
+        """Map the peers' gathered buffers and prove the mapping with a round of marker writes; True on every rank
+        or False on every rank (``allgather_obj`` carries the verdicts).  On success ``collective`` becomes "p2p";
+        ``result()`` is then only complete after the launcher's barrier (all ranks synced, then a process barrier)."""
+        ok = True
+        try:
+            self.peers = PeerMap(self.ctx, self.rank, self.world, self.gathered, allgather_obj)
+        except Exception as exc:   # noqa: BLE001 - any rank may fail to map; the verdict is agreed below
+            self.peers, ok = None, False
+            self.p2p_error = str(exc)
+        verdicts = allgather_obj(ok)
+        if not all(verdicts):
+            if self.peers is not None:
+                self.peers.close()
+                self.peers = None
+            return False
+        # marker round: every rank writes rank+1 into the first bytes of its slot everywhere, then checks all slots
+        mark = np.full(16, self.rank + 1, np.uint8)
+        for b in range(len(self.gathered)):
+            self._slots[b].upload(mark)
+            self.peers.push(self._slots[b], self.slot_bytes, b)    # the whole slot: the offset is rank * slot_bytes
+        barrier()
+        good = True
+        for g in self.gathered:
+            raw = g.download(np.uint8, (self.world, self.slot_bytes))
+            good = good and all((raw[r, :16] == r + 1).all() for r in range(self.world))
+        for g in self.gathered:                                  # back to "no match" everywhere before real passes
+            check(self.ctx.lib.slam_memset(self.ctx.handle, g.ptr, 0xFF, g.nbytes))
+        self.ctx.sync()
+        verdicts = allgather_obj(bool(good))
+        barrier()
+        if not all(verdicts):
+            self.peers.close()
+            self.peers = None
+            return False
+        self.collective = "p2p"
+        return True
+
+
+class ShardedMatcher(_Gathering):
     """knn=2 search of a query set sharded over ``world`` GPUs against a replicated train set.
 
     ``collective``: "rccl" (communicator made by ``init_comm``), "p2p" (peer copies over HIP IPC, enabled with
@@ -151,6 +204,7 @@ class ShardedMatcher:
             check(ctx.lib.slam_memset(ctx.handle, g.ptr, 0xFF, g.nbytes))
             self.my_idx.append(g.view(off, per * 8))
             self.my_dist.append(g.view(off + per * 8, per * 8))
+        self._slots = self.my_idx            # a slot starts with its idx rows
         self.passes = 0
         self.last = 0
 
@@ -163,51 +217,9 @@ class ShardedMatcher:
         if self.n_local:
             knn2_device(ctx, self.d_query.buf, self.n_local, self.d_train.buf, self.n_train, self.my_idx[b],
                         self.my_dist[b])
-        if self.collective == "rccl":
-            check(ctx.lib.slam_comm_allgather_overlapped(ctx.handle, self.my_idx[b].ptr, self.gathered[b].ptr,
-                                                         self.slot_bytes, b))
-        elif self.collective == "p2p":
-            self.peers.push(self.my_idx[b], self.slot_bytes, b)
+        self._gather(b)
         self.last = b
         self.passes += 1
-
-    def enable_p2p(self, allgather_obj: Callable[[object], list], barrier: Callable[[], None]) -> bool:
-        """Map the peers' gathered buffers and prove the mapping with a round of marker writes; True on every rank
-        or False on every rank (``allgather_obj`` carries the verdicts).  On success ``collective`` becomes "p2p";
-        ``result()`` is then only complete after the launcher's barrier (all ranks synced, then a process barrier)."""
-        ok = True
-        try:
-            self.peers = PeerMap(self.ctx, self.rank, self.world, self.gathered, allgather_obj)
-        except Exception as exc:   # noqa: BLE001 - any rank may fail to map; the verdict is agreed below
-            self.peers, ok = None, False
-            self.p2p_error = str(exc)
-        verdicts = allgather_obj(ok)
-        if not all(verdicts):
-            if self.peers is not None:
-                self.peers.close()
-                self.peers = None
-            return False
-        # marker round: every rank writes rank+1 into the first bytes of its slot everywhere, then checks all slots
-        mark = np.full(16, self.rank + 1, np.uint8)
-        for b, g in enumerate(self.gathered):
-            self.my_idx[b].upload(mark)
-            self.peers.push(self.my_idx[b], self.slot_bytes, b)    # the whole slot: the offset is rank * slot_bytes
-        barrier()
-        good = True
-        for g in self.gathered:
-            raw = g.download(np.uint8, (self.world, self.slot_bytes))
-            good = good and all((raw[r, :16] == r + 1).all() for r in range(self.world))
-        for g in self.gathered:                                  # back to "no match" everywhere before real passes
-            check(self.ctx.lib.slam_memset(self.ctx.handle, g.ptr, 0xFF, g.nbytes))
-        self.ctx.sync()
-        verdicts = allgather_obj(bool(good))
-        barrier()
-        if not all(verdicts):
-            self.peers.close()
-            self.peers = None
-            return False
-        self.collective = "p2p"
-        return True
 
     def result(self) -> Tuple[np.ndarray, np.ndarray]:
         """The complete [N,2] tables of the most recent pass (waits for both streams)."""
@@ -227,6 +239,62 @@ class ShardedMatcher:
             self.peers = None
         for g in self.gathered:
             g.free()
+        self.d_query.free()
+        self.d_train.free()
+
+
+class TrainShardedMatcher(_Gathering):
+    """The other partitioning of SURVEY.md §8e, for train sets much larger than the query set (or too large for one
+    GPU): rank g searches ALL query rows against its own slice of the train rows, reporting global train indices
+    (``train_base``); the per-rank top-2 tables are all-gathered (8*N bytes per rank and table) and every rank merges
+    them by (distance, index) with ``slam_bf_merge_top2`` - the order that keeps OpenCV's lowest-index tie rule
+    across shards, so the result is bit-identical to the single-GPU search."""
+
+    def __init__(self, ctx: Context, rank: int, world: int, query, train_shard, train_base: int,
+                 collective: Optional[str] = "rccl"):
+        self.ctx, self.rank, self.world = ctx, rank, world
+        self.collective = collective if world > 1 else None
+        self.peers: Optional[PeerMap] = None
+        query, train_shard = as_descriptors(query), as_descriptors(train_shard)
+        self.n, self.m_local, self.train_base = query.shape[0], train_shard.shape[0], int(train_base)
+        self.d_query = DeviceDescriptors(ctx, query)
+        self.d_train = DeviceDescriptors(ctx, train_shard)
+        self.slot_bytes = max(self.n, 1) * 8
+        self.gathered = [ctx.malloc(self.slot_bytes * world) for _ in range(2)]   # [0]: idx tables, [1]: dist tables
+        for g in self.gathered:
+            check(ctx.lib.slam_memset(ctx.handle, g.ptr, 0xFF, g.nbytes))         # idx -1 = "no neighbour" until filled
+        self._slots = [g.view(rank * self.slot_bytes, self.slot_bytes) for g in self.gathered]
+        self.out_idx, self.out_dist = ctx.malloc(self.slot_bytes), ctx.malloc(self.slot_bytes)
+
+    def step(self) -> None:
+        """Local search over this rank's train slice, then the gathers of both tables (all asynchronous)."""
+        ctx = self.ctx
+        if self.collective:
+            for b in (0, 1):
+                check(ctx.lib.slam_comm_wait_buffer(ctx.handle, b))
+        if self.n:
+            knn2_device(ctx, self.d_query.buf, self.n, self.d_train.buf, self.m_local, self._slots[0], self._slots[1],
+                        self.train_base)
+        for b in (0, 1):
+            self._gather(b)
+
+    def result(self) -> Tuple[np.ndarray, np.ndarray]:
+        """Merged [N,2] tables.  With peer copies call this after the launcher's barrier (see ``enable_p2p``)."""
+        if self.n == 0:
+            return np.zeros((0, 2), np.int32), np.zeros((0, 2), np.int32)
+        c = self.ctx
+        c.sync()
+        check(c.lib.slam_bf_merge_top2(c.handle, self.gathered[0].ptr, self.gathered[1].ptr, self.world, self.n,
+                                       self.out_idx.ptr, self.out_dist.ptr))
+        return self.out_idx.download(np.int32, (self.n, 2)), self.out_dist.download(np.int32, (self.n, 2))
+
+    def free(self) -> None:
+        self.ctx.sync()
+        if self.peers is not None:
+            self.peers.close()
+            self.peers = None
+        for b in (*self.gathered, self.out_idx, self.out_dist):
+            b.free()
         self.d_query.free()
         self.d_train.free()
 

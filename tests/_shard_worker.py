@@ -1,0 +1,66 @@
+"""Worker for test_comm_gpu.py: one rank of a sharded search (run under torch.distributed.run; every rank on GPU 0).
+
+Not collected by pytest (leading underscore).  argv[1] = "query" | "train": which partitioning to run.  The ranks
+gather through the peer-copy tier (RCCL refuses ranks that share a GPU) and compare with the oracle."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(ROOT, "slam-experiments_amd"), ROOT):
+    sys.path.insert(0, p)
+
+
+def main() -> int:
+    import torch.distributed as dist
+
+    import slamhip
+    from oracle import oracle
+    from slamhip.dist import ShardedMatcher, TrainShardedMatcher
+
+    mode = sys.argv[1]
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ctx = slamhip.Context(0)
+
+    def allgather_obj(x):
+        out = [None] * world
+        dist.all_gather_object(out, x)
+        return out
+
+    def barrier():
+        ctx.sync()
+        dist.barrier()
+
+    rng = np.random.default_rng(99)
+    n, m = (3001, 7000) if mode == "query" else (500, 9001)     # ragged on purpose: tail shards are shorter
+    query = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    train = rng.integers(0, 256, (m, 32), dtype=np.uint8)
+    train[m // 2:m // 2 + 50] = train[:50]                      # duplicates across the shard boundary: tie rule
+    query[:50] = train[:50]
+    if mode == "query":
+        sm = ShardedMatcher(ctx, rank, world, query, train, collective=None)
+    else:
+        per = (m + world - 1) // world
+        a, b = min(rank * per, m), min((rank + 1) * per, m)
+        sm = TrainShardedMatcher(ctx, rank, world, query, train[a:b], a, collective=None)
+    ok = sm.enable_p2p(allgather_obj, barrier)
+    for _ in range(3):                                           # several passes: buffers are reused
+        sm.step()
+    barrier()
+    idx, d = sm.result()
+    ei, ed = oracle.bf_knn_c(query, train, 2, threads=4)
+    good = bool(ok and sm.collective == "p2p" and np.array_equal(idx, ei) and np.array_equal(d, ed))
+    barrier()
+    sm.free()
+    ctx.close()
+    verdicts = allgather_obj(good)
+    dist.destroy_process_group()
+    if rank == 0:
+        print("SHARD_WORKER_OK" if all(verdicts) else f"SHARD_WORKER_FAILED {verdicts}")
+    return 0 if all(verdicts) else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -77,3 +77,14 @@ def test_two_ranks_on_one_gpu_take_the_loud_fallbacks(built, force, expect):
     assert rec["n_gpus"] == 2 and rec["parity_spot_check"] is True
     assert rec["config"]["collective"] in expect, (rec["config"]["collective"], out.stderr[-2000:])
     assert rec["cpu_baseline"] is None
+
+
+@pytest.mark.parametrize("mode,port", [("query", "29641"), ("train", "29643")])
+def test_sharded_matchers_between_processes(built, mode, port):
+    """Three ranks on GPU 0 under torch.distributed.run: the query-sharded and the train-sharded matcher of
+    slamhip.dist gather through IPC peer copies (ragged shards, several passes) and must equal the oracle."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr",
+           "127.0.0.1", "--master-port", port, os.path.join(ROOT, "tests", "_shard_worker.py"), mode]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0 and "SHARD_WORKER_OK" in out.stdout, (out.stdout[-500:], out.stderr[-2500:])
