@@ -5,23 +5,30 @@
 
 A "step" is one pass of the hot path over one batch: all 65536 query descriptors matched
 (knn=2) against 65536 train descriptors, inputs resident in HBM before the timed region.
-At N > 1 the driver starts one process per GPU (torch.distributed.run); the query rows are
-sharded across ranks, every rank holds the 2 MiB train set, and each step ends with the RCCL
-all-gather of the per-shard top-2 rows, so every rank owns the full result (strong scaling:
-the total work is fixed).  torch is used only for the rendezvous (gloo): the data path is
-libslamhip.so + librccl.
+At N > 1 there is one process per GPU: the query rows are sharded across ranks, every rank
+holds the 2 MiB train set, and each step ends with the RCCL all-gather of the per-shard top-2
+rows, so every rank owns the full result (strong scaling: the total work is fixed).
+
+`python bench.py --gpus N` is self-contained: with no WORLD_SIZE in the environment it starts
+the N rank processes itself (before anything touches a GPU).  Under the driver's launcher
+(`python -m torch.distributed.run ... bench.py --gpus N`) the ranks already exist and only their
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_PORT variables are read.  Either way the rendezvous, the
+barriers and the max-over-ranks are `slamhip.launch` (a Unix socket, standard library): no torch,
+no MPI on the control or the data path; the data path is libslamhip.so + librccl.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline      — the dominant kernel (bf_top2_kernel) against the HBM roofline on ALGORITHMIC
                   bytes, as the contract asks, plus the VALU-integer figures that actually bound it;
   cpu_baseline  — the CPU oracle (oracle/bf_hamming_oracle.c, a port: cv2 is not installable
-                  here) timed on the host cores over the same arrays;
+                  here) timed on the host cores over the same arrays (N = 1 only);
+  pipelined     — the same searches issued alternately on two contexts (N = 1 only; reported, not `value`);
   reproj        — the second hot path (residual/Jacobian build, 200 poses x 50k points dense)
-                  with its own HBM roofline (only with --reproj or at the default N=1 run).
+                  with its own HBM roofline (only at the default N=1 run).
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -46,18 +53,33 @@ OPS_PER_PAIR = 16                 # 8 v_xor + 8 v_bcnt per 256-bit pair (algorit
 # measured issue cost (tools/ubench/valu_rate.hip): v_xor 2 cycles, v_bcnt 4 cycles per wave64
 CYCLES_PER_PAIRSTEP = 8 * 2 + 8 * 4
 ROW_LOOP_CYCLES = 54.8            # measured: isolated [lgkmcnt wait, 8 v_xor, 8 v_bcnt, 2 ds_read_b128] row loop, 2.38 GHz
+SPIN_UP_PASSES = 24               # the GPU needs ~10 passes (~20 ms) of load before DVFS reaches its steady clock (tools/ramp.py)
+HBM_COUNTERS = os.path.join(ROOT, "profiles", "r02_hbm_counters.json")
+KERNEL_SOURCES = {"bf_top2_kernel": "bf_hamming.hip", "reproj_rj_kernel": "reproj.hip"}
+
+
+def source_sha(name: str) -> str:
+    with open(os.path.join(ROOT, "slam-experiments_amd", "csrc", name), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
 
 
 def profiled_traffic(kernel: str):
-    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/), or None.
+    """(HBM-side bytes per launch of `kernel`, where they come from) from the committed rocprofv3 PMC passes, or
+    (None, why not).
 
-    PMC counters cannot be collected from inside this process; the separate FETCH_SIZE / WRITE_SIZE passes
-    over this same command are summarised (with the gfx950 corrections) in profiles/r01_hbm_counters.json."""
+    PMC counters cannot be collected from inside this process; the separate FETCH_SIZE / WRITE_SIZE passes over this
+    same command are summarised (with the gfx950 corrections) by tools/pmc_summary.py, which stamps the file with the
+    hash of the kernel source it was collected on.  A stamp that no longer matches the source means the numbers
+    describe an older kernel: they are then withheld instead of printed."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_hbm_counters.json")) as f:
-            return float(json.load(f)[kernel]["traffic_bytes"])
-    except (OSError, KeyError, ValueError):
-        return None
+        with open(HBM_COUNTERS) as f:
+            rec = json.load(f)
+        want, have = rec["source_sha"][KERNEL_SOURCES[kernel]], source_sha(KERNEL_SOURCES[kernel])
+        if want != have:
+            return None, f"{os.path.relpath(HBM_COUNTERS, ROOT)} was collected on {KERNEL_SOURCES[kernel]} {want}, the source is now {have}"
+        return float(rec[kernel]["traffic_bytes"]), f"{os.path.relpath(HBM_COUNTERS, ROOT)} (rocprofv3 PMC, separate passes, N=1 launch, source {have})"
+    except (OSError, KeyError, ValueError) as exc:
+        return None, f"no usable PMC summary ({type(exc).__name__}: {exc})"
 
 
 def make_descriptors(n: int, seed: int) -> np.ndarray:
@@ -151,10 +173,11 @@ def reproj_bench(ctx, steps: int, warmup: int, cpu: bool = True) -> dict:
     meas = rng.uniform(0, 752, (O, 2)).astype(np.int32).astype(np.float64)   # int-truncated pixels (primitives.py:110-112)
     prob = slamhip.ReprojProblem(ctx, poses, points, obs_pose, obs_point, meas,
                                  (458.654, 457.296, 367.215, 248.375), with_point=True)
-    for _ in range(warmup):
+    ctx.prof_enable(True)
+    for _ in range(SPIN_UP_PASSES * 4 + warmup):         # same clock spin-up as the matcher gets (a pass is 0.27 ms here)
         prob.linearize()
     ctx.sync()
-    ctx.prof_enable(True)
+    ctx.prof_read()
     ctx.timer_start()
     for _ in range(steps):
         prob.linearize()
@@ -165,15 +188,53 @@ def reproj_bench(ctx, steps: int, warmup: int, cpu: bool = True) -> dict:
     bytes_per_obs = 4 + 4 + 16 + 16 + 96 + 48           # two indices + pixel read; e, J_pose, J_point written
     kernel_ms = kms / max(launches, 1)
     gbs = O * bytes_per_obs / (kernel_ms * 1e-3) / 1e9
+    traffic, traffic_source = profiled_traffic("reproj_rj_kernel")
     out = {"workload": "200 poses x 50000 points dense = 1e7 observations, e + J_pose(2x6) + J_point(2x3), f64",
            "observations_per_s": O / (ms * 1e-3), "ms_per_step": ms, "kernel_ms": kernel_ms,
            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": gbs / HBM_PEAK_GBS, "traffic": profiled_traffic("reproj_rj_kernel"),
+                        "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                         "bytes_per_observation": bytes_per_obs}}
     if cpu:
         out["cpu_baseline"] = reproj_cpu_baseline(poses, points, obs_pose, obs_point, meas,
                                                   (458.654, 457.296, 367.215, 248.375))
     return out
+
+
+def pipelined_leg(query, train, steps: int) -> dict:
+    """The same 64k x 64k searches issued alternately on two contexts of the one GPU (two streams, two merge states):
+    the drain of one launch overlaps the start of the next.  Reported beside `value`, never as `value`: the contract's
+    roofline is per kernel launch, and overlapped launches stretch each other."""
+    import slamhip
+
+    ctxs = [slamhip.Context(0 if os.environ.get("SLAM_BENCH_SINGLE_DEVICE") == "1" else int(os.environ.get("LOCAL_RANK", "0")))
+            for _ in range(2)]
+    sets = []
+    for c in ctxs:
+        sets.append((c, slamhip.DeviceDescriptors(c, query), slamhip.DeviceDescriptors(c, train), slamhip.Top2Table(c, N_QUERY)))
+
+    def one(i):
+        c, dq, dt, tab = sets[i & 1]
+        slamhip.knn2_device(c, dq.buf, N_QUERY, dt.buf, N_TRAIN, tab.idx, tab.dist)
+
+    for i in range(SPIN_UP_PASSES):
+        one(i)
+    for c in ctxs:
+        c.sync()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        one(i)
+    for c in ctxs:
+        c.sync()
+    ms = (time.perf_counter() - t0) * 1e3 / steps
+    a, b = sets[0][3].download(), sets[1][3].download()
+    same = bool(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]))
+    for c, dq, dt, tab in sets:
+        for o in (tab, dq, dt):
+            o.free()
+        c.close()
+    return {"value": float(N_QUERY) * N_TRAIN / (ms * 1e-3), "unit": "pairs/s", "ms_per_step": ms, "steps": steps,
+            "streams": 2, "tables_identical": same,
+            "note": "searches alternate between two contexts (streams) of the same GPU; wall time / steps"}
 
 
 def main() -> int:
@@ -183,22 +244,22 @@ def main() -> int:
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reproj", action="store_true")
+    ap.add_argument("--no-pipelined", action="store_true")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from slamhip.launch import Rendezvous, from_env, spawn_ranks
+
+    if args.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and "SLAM_RDZV" not in os.environ:
+        # self-contained launch: this parent never touches a GPU, it starts one process per rank and relays rank 0's line
+        return spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus)
+
+    rank, local_rank, world, rdzv_name = from_env()
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    rz = Rendezvous(rank, world, rdzv_name or "single")
 
     import slamhip
     from slamhip.dist import ShardedMatcher, init_comm
-
-    dist = None
-    if world > 1:
-        import torch.distributed as dist  # rendezvous only (gloo over 127.0.0.1); the data path is RCCL inside libslamhip
-
-        dist.init_process_group("gloo", rank=rank, world_size=world)
 
     # SLAM_BENCH_SINGLE_DEVICE=1 (tests on a 1-GPU box): every rank uses GPU 0
     ctx = slamhip.Context(0 if os.environ.get("SLAM_BENCH_SINGLE_DEVICE") == "1" else local_rank)
@@ -206,65 +267,47 @@ def main() -> int:
 
     def barrier():
         ctx.sync()
-        if dist is not None:
-            dist.barrier()
+        rz.barrier()
 
     collective = "none"
     rccl_ok = False
     if world > 1:
-        import torch
-
-        def bcast(ident):
-            box = [ident]
-            dist.broadcast_object_list(box, src=0)
-            return box[0]
-
-        def allgather_obj(x):
-            out = [None] * world
-            dist.all_gather_object(out, x)
-            return out
-
         # RCCL is the data path.  If its communicator cannot be created on this node, say so loudly and use the
         # library's own direct all-gather over xGMI peer mappings (HIP IPC); if that cannot be set up either,
-        # gather through the host (gloo), so that a scaling number - labelled as such - still exists.
-        force = os.environ.get("SLAM_BENCH_COLLECTIVE", "")    # test hook: "p2p" / "gloo" skip the tiers above them
+        # gather through the host, so that a scaling number - labelled as such - still exists.
+        force = os.environ.get("SLAM_BENCH_COLLECTIVE", "")    # test hook: "p2p" / "host" skip the tiers above them
         try:
-            if force in ("p2p", "gloo"):
+            if force in ("p2p", "host"):
                 raise RuntimeError(f"skipped: SLAM_BENCH_COLLECTIVE={force}")
-            init_comm(ctx, rank, world, bcast)
+            init_comm(ctx, rank, world, rz.bcast)
             failed = 0
         except Exception as exc:   # noqa: BLE001 - any failure of the native init
             print(f"[bench] rank {rank}: RCCL communicator init failed ({exc}); trying peer copies over HIP IPC", file=sys.stderr)
             failed = 1
-        flag = torch.tensor([failed])
-        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-        rccl_ok = not int(flag[0])
+        rccl_ok = not max(rz.allgather(failed))                # every rank reaches this collective on every path
         if not rccl_ok:
             ctx.lib.slam_comm_destroy(ctx.handle)
 
     sm = ShardedMatcher(ctx, rank, world, query, train, collective="rccl" if rccl_ok else None)
     if world > 1 and rccl_ok:
         collective = "rccl"
-    elif world > 1 and os.environ.get("SLAM_BENCH_COLLECTIVE") != "gloo" and sm.enable_p2p(allgather_obj, barrier):
+    elif world > 1 and os.environ.get("SLAM_BENCH_COLLECTIVE") != "host" and sm.enable_p2p(rz.allgather, barrier):
         collective = "xgmi-p2p-copies"
     elif world > 1:
-        collective = "gloo-host-fallback"
+        collective = "host-fallback"
         print(f"[bench] rank {rank}: peer mapping failed too ({getattr(sm, 'p2p_error', 'marker check')}); gathering through the host", file=sys.stderr)
         device_step = sm.step
 
         def host_gather_step():
             device_step()
-            mine = torch.from_numpy(sm.gathered[sm.last].view(rank * sm.slot_bytes, sm.slot_bytes).download(np.uint8, (sm.slot_bytes,)))
-            parts = [torch.empty_like(mine) for _ in range(world)]
-            dist.all_gather(parts, mine)
-            sm.host_table = torch.cat(parts).numpy()
+            mine = sm.gathered[sm.last].view(rank * sm.slot_bytes, sm.slot_bytes).download(np.uint8, (sm.slot_bytes,))
+            sm.host_table = np.concatenate(rz.allgather(mine))
 
         sm.step = host_gather_step
 
-    # device spin-up, not part of the measurement: the GPU needs ~10 passes (~20 ms) of load before DVFS
-    # reaches its steady clock (tools/ramp.py: 3.0, 2.1, 2.0 ... 1.76 ms per pass from idle)
+    # device spin-up, not part of the measurement (see SPIN_UP_PASSES)
     ctx.prof_enable(True)              # creates the event pool now, so that no idle gap precedes the timed region
-    for _ in range(24):
+    for _ in range(SPIN_UP_PASSES):
         sm.step()
     barrier()
     for _ in range(args.warmup):
@@ -281,15 +324,11 @@ def main() -> int:
     launches, kernel_ms_total = ctx.prof_read()
     ctx.prof_enable(False)
 
-    if dist is not None:
-        import torch
-
-        tmax = torch.tensor([wall_ms, dev_ms], dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        wall_ms, dev_ms = float(tmax[0]), float(tmax[1])
+    times = rz.allgather((wall_ms, dev_ms))                    # MAX over ranks
+    wall_ms, dev_ms = max(t[0] for t in times), max(t[1] for t in times)
 
     # correctness of what was timed: full table on every rank, spot-checked against the oracle on rank 0
-    if collective == "gloo-host-fallback":
+    if collective == "host-fallback":
         raw = sm.host_table.view(np.int32).reshape(world, 2, sm.per, 2)
         idx = np.ascontiguousarray(raw[:, 0].reshape(world * sm.per, 2)[:N_QUERY])
         dist_tab = np.ascontiguousarray(raw[:, 1].reshape(world * sm.per, 2)[:N_QUERY])
@@ -314,6 +353,7 @@ def main() -> int:
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
         lane_ops = local_pairs * OPS_PER_PAIR / (kernel_ms * 1e-3)
         cyc_floor_ms = local_pairs / 64 * CYCLES_PER_PAIRSTEP / (256 * 4) / 2.4e9 * 1e3
+        traffic, traffic_source = profiled_traffic("bf_top2_kernel") if world == 1 else (None, "PMC passes are collected at N=1 only")
         out = {
             "metric": "descriptor pairs/sec BF-Hamming knn=2 @64kx64k",
             "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -323,14 +363,13 @@ def main() -> int:
                                    "BF-Hamming knn=2 (BASELINE configs[2])",
                        "n_query": N_QUERY, "n_train": N_TRAIN,
                        "sharding": f"query rows / {world}, train replicated, all-gather of top-2" if world > 1 else "single GPU",
-                       "collective": collective},
+                       "collective": collective, "launch_plan": ctx.plan_info(max(sm.n_local, 1), N_TRAIN)},
             "device_ms_per_step": dev_ms / args.steps,
             "parity_spot_check": ok,
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": profiled_traffic("bf_top2_kernel") if world == 1 else None,
-                "traffic_source": "profiles/r01_hbm_counters.json (rocprofv3 PMC, separate passes, N=1 launch)",
+                "traffic": traffic, "traffic_source": traffic_source,
                 "kernel": "bf_top2_kernel", "kernel_ms": kernel_ms, "launches": launches,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "note": "contractual HBM figure on algorithmic bytes; the kernel is VALU-integer bound "
@@ -343,20 +382,24 @@ def main() -> int:
                              "isolated_row_loop_cycles": ROW_LOOP_CYCLES,
                              "frac_of_isolated_row_loop": (local_pairs / 64 * ROW_LOOP_CYCLES / (256 * 4) / 2.38e9 * 1e3) / kernel_ms}},
         }
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(query, train)
+        if world > 1:
+            out["cpu_baseline"] = None
+            out["cpu_baseline_note"] = "the CPU leg is timed at N=1 only (same arrays; see the N=1 line)"
         elif not args.no_cpu_baseline:
-            out["cpu_baseline"] = None   # timed at N=1 only
-    sm.free()
+            out["cpu_baseline"] = cpu_baseline(query, train)
+    sm.free(barrier)                   # unmap peers -> barrier -> free the exported buffers (HIP IPC teardown order)
+    if rank == 0 and world == 1 and not args.no_pipelined:
+        out["pipelined"] = pipelined_leg(query, train, max(args.steps, 20))
     if rank == 0 and world == 1 and not args.no_reproj:
-        out["reproj"] = reproj_bench(ctx, max(3, min(args.steps, 20)), 2, cpu=not args.no_cpu_baseline)
+        out["reproj"] = reproj_bench(ctx, max(3, min(args.steps, 20)), args.warmup, cpu=not args.no_cpu_baseline)
+    check_rc = 0
     if world > 1:
         check_rc = ctx.lib.slam_comm_destroy(ctx.handle) if collective == "rccl" else 0
-        dist.barrier()
-        dist.destroy_process_group()
-        if check_rc:
-            raise SystemExit("slam_comm_destroy failed")
+        rz.barrier()
+    rz.close()
     ctx.close()
+    if check_rc:
+        raise SystemExit("slam_comm_destroy failed")
     if rank == 0:
         print(json.dumps(out))
         if not ok:

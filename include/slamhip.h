@@ -112,10 +112,24 @@ SLAM_API int slam_bf_knn2_u256_host(slam_ctx* ctx, const uint8_t* h_query, int64
                            const uint8_t* h_train, int64_t M,
                            int32_t* h_idx, int32_t* h_dist);
 
-/* Tuning override for experiments: R = queries per lane (0 = shipped choice, 1;
- * or 1, 2, 4, 8), blocks_per_cu = grid size target (0 = shipped choice: 32, or
- * 64 for query sets with fewer query blocks than CUs).  Process-wide. */
-SLAM_API int slam_bf_set_tuning(int R, int blocks_per_cu);
+/* Tuning overrides for experiments, per context.  h_knobs is an int32 array of up to SLAM_BF_KNOBS entries (missing
+ * entries and a NULL array mean 0 = the shipped choice):
+ *   [0] R             queries per lane: 1, 2, 4 or 8 (shipped: 1)
+ *   [1] blocks_per_cu grid size target (shipped: 32, or 64 for query sets with fewer query blocks than CUs)
+ *   [2] lead_rows     train rows given to the leader chunks, which are dispatched first, run at raised wave priority
+ *                     and publish exact per-query bounds (shipped: M/16 up to 4096 for M >= 16384, none below);
+ *                     -1 = no leaders
+ *   [3] lead_chunk    rows per leader chunk, a multiple of 32 (shipped: about one leader block per CU)
+ *   [4] lead_prio     s_setprio level of the leader blocks: 1..3 (shipped: 3); -1 = leave them at priority 0
+ *   [5] tail          number of linearly shrinking chunks at the end of the grid; -1 / 0 = none (shipped) */
+#define SLAM_BF_KNOBS 6
+SLAM_API int slam_bf_set_tuning(slam_ctx* ctx, const int32_t* h_knobs, int count);
+/* The launch plan slam_bf_knn2_u256 would use for N x M on this context: h_plan int32 [8] =
+ * {R, query blocks, uniform chunk rows, chunks, leader rows, leader chunks, shrinking tail chunks, CUs}. */
+SLAM_API int slam_bf_plan_info(slam_ctx* ctx, int64_t N, int64_t M, int32_t* h_plan);
+/* Restore the matcher's per-context merge state to its idle values.  Every search leaves it clean by itself;
+ * call this after a search failed part-way (the library does so on a failed launch).  Stream-ordered. */
+SLAM_API int slam_bf_reset_state(slam_ctx* ctx);
 
 /* Post-match selection on the device (feature_matchers.py:41-43 and the
  * OpenCV knn / ratio semantics).  Input: the [N,2] tables above.
@@ -128,14 +142,14 @@ SLAM_API int slam_bf_match_filter(slam_ctx* ctx, const int32_t* d_idx, const int
                          int64_t N, int mode, double param,
                          uint8_t* d_keep, int64_t* h_count, int32_t* h_min_dist);
 
-/* crossCheck=True selection (cv2.BFMatcher(normType, crossCheck=True).match):
- * given the REVERSE search (every train row's nearest query, [M,2] tables from
- * slam_bf_knn2_u256(train as query, query as train)), each query q receives the
- * train row t with the smallest (dist, t) among rows whose nearest query is q;
- * queries chosen by no train row get idx -1.  d_out_idx / d_out_dist are
- * int32 [N].  Synchronises. */
-SLAM_API int slam_bf_cross_check(slam_ctx* ctx, const int32_t* d_rev_idx, const int32_t* d_rev_dist,
-                        int64_t M, int64_t N, int32_t* d_out_idx, int32_t* d_out_dist,
+/* crossCheck=True selection (cv2.BFMatcher(normType, crossCheck=True).match; OpenCV 4.x batch_distance.cpp
+ * crosscheck branch): given the FORWARD search (every query row's nearest train row, [N,2] tables from
+ * slam_bf_knn2_u256(query, train)) and the REVERSE search (every train row's nearest query row, [M,2] idx table
+ * from slam_bf_knn2_u256(train as query, query as train)), query q keeps its nearest train row t iff q is also
+ * t's nearest query row (mutual nearest neighbours, ties to the lowest index on both sides); all other queries
+ * get (-1, INT32_MAX).  d_out_idx / d_out_dist are int32 [N].  Synchronises. */
+SLAM_API int slam_bf_cross_check(slam_ctx* ctx, const int32_t* d_fwd_idx, const int32_t* d_fwd_dist, int64_t N,
+                        const int32_t* d_rev_idx, int64_t M, int32_t* d_out_idx, int32_t* d_out_dist,
                         int64_t* h_count);
 
 /* ---- hot path 2: reprojection residual + Jacobians (f64) ---------------- */
@@ -191,6 +205,10 @@ SLAM_API int slam_pose_optimize_f64(slam_ctx* ctx, const double* d_pose_in, cons
 SLAM_API int slam_bf_match_host(slam_ctx* ctx, const uint8_t* h_query, int64_t N, const uint8_t* h_train,
                                 const void* d_train, int64_t M, void* d_query_keep, int mode, double param,
                                 int32_t* h_query_idx, int32_t* h_train_idx, float* h_distance, int64_t* h_count);
+/* Bytes the host-buffer entry points (slam_bf_knn2_u256_host, slam_bf_match_host, slam_pose_optimize_host_f64)
+ * have moved over PCIe on this context since it was created: inputs copied or read in place by the kernels
+ * (h2d), results copied or written in place (d2h).  Rows passed as device pointers (d_train) count nothing. */
+SLAM_API int slam_io_counters(slam_ctx* ctx, uint64_t* h2d_bytes, uint64_t* d2h_bytes);
 /* slam_pose_optimize_f64 on host buffers (Frontend._correct_current_pose, frontend.py:298-393): h_pose_in [12],
  * h_points [O,3], h_meas [O,2] -> h_pose_out [12], h_inlier uint8 [O], h_chi2 [O], h_stats int32 [2]. */
 SLAM_API int slam_pose_optimize_host_f64(slam_ctx* ctx, const double* h_pose_in, const double* h_points,

@@ -23,9 +23,14 @@
  *       to the lowest index; dist initialised INT_MAX, idx -1.
  *   - multi-image train sets: images scanned in order, index encoded
  *       imgIdx << 18 | trainIdx (IMGIDX_SHIFT = 18 in matchers.cpp).
- *   - crossCheck=True: batch_distance.cpp crosscheck branch (K == 1): reverse
- *       1-NN per train row, then for train rows in ascending order
- *       "if d < dist[q]: dist[q] = d, idx[q] = t".
+ *   - crossCheck=True: batch_distance.cpp crosscheck branch (K == 1), OpenCV
+ *       4.x: the reverse 1-NN per train row (tdist/tidx) AND the forward 1-NN
+ *       per query row (sdist/sidx) are computed; train rows are scanned in
+ *       ascending order with "if d < dist[q]: dist[q] = d, idx[q] = t"; then
+ *       every query i with tidx[sidx[i]] != i has its idx cleared to -1.  The
+ *       result is the documented contract of BFMatcher(crossCheck=True): pair
+ *       (i, j) is returned iff j is the nearest train row of i AND i is the
+ *       nearest query row of j (ties -> lowest index on both sides).
  */
 #include <stdint.h>
 #include <stdlib.h>
@@ -193,15 +198,25 @@ int64_t oracle_bf_ratio_test(const int32_t* idx, const int32_t* dist, int64_t N,
     return n;
 }
 
-/* crossCheck=True match(query, train): out_idx/out_dist int32 [N], -1 / INT_MAX
- * where the query is chosen by no train row. */
+/* crossCheck=True match(query, train): out_idx/out_dist int32 [N], (-1, INT_MAX)
+ * where the query has no mutual nearest neighbour.  Follows batchDistance's
+ * crosscheck branch step by step: reverse table, forward table, one-pass
+ * scatter over ascending train rows (strict <), then the forward-consistency
+ * pass "if (tidx[sidx[i]] != i) nidx[i] = -1".  (OpenCV leaves the scattered
+ * distance behind for cleared rows; it is never reported because knnMatchImpl
+ * stops at nidx < 0, so INT_MAX is stored here instead.) */
 int oracle_bf_cross_check_u256(const uint8_t* q, int64_t N, const uint8_t* t, int64_t M, int32_t* out_idx,
                                int32_t* out_dist, int threads) {
-    int32_t* tidx = (int32_t*)malloc((size_t)(M > 0 ? M : 1) * sizeof(int32_t));
-    int32_t* tdist = (int32_t*)malloc((size_t)(M > 0 ? M : 1) * sizeof(int32_t));
-    if (!tidx || !tdist) { free(tidx); free(tdist); return -1; }
+    const size_t mm = (size_t)(M > 0 ? M : 1), nn = (size_t)(N > 0 ? N : 1);
+    int32_t* tidx = (int32_t*)malloc(mm * sizeof(int32_t));
+    int32_t* tdist = (int32_t*)malloc(mm * sizeof(int32_t));
+    int32_t* sidx = (int32_t*)malloc(nn * sizeof(int32_t));
+    int32_t* sdist = (int32_t*)malloc(nn * sizeof(int32_t));
+    if (!tidx || !tdist || !sidx || !sdist) { free(tidx); free(tdist); free(sidx); free(sdist); return -1; }
     /* batchDistance(src2, src1, tdist, tidx, K=1): every train row's nearest query */
     oracle_bf_knn_u256(t, M, q, N, 1, tidx, tdist, threads);
+    /* batchDistance(src1, src2, sdist, sidx, K=1): every query row's nearest train row */
+    oracle_bf_knn_u256(q, N, t, M, 1, sidx, sdist, threads);
     for (int64_t i = 0; i < N; i++) { out_idx[i] = -1; out_dist[i] = INT_MAX; }
     for (int64_t i = 0; i < M; i++) {
         const int qi = tidx[i];
@@ -212,7 +227,16 @@ int oracle_bf_cross_check_u256(const uint8_t* q, int64_t N, const uint8_t* t, in
             out_idx[qi] = (int32_t)i;
         }
     }
+    for (int64_t i = 0; i < N; i++) {
+        const int si = sidx[i];
+        if (si < 0 || tidx[si] != (int32_t)i) {
+            out_idx[i] = -1;
+            out_dist[i] = INT_MAX;
+        }
+    }
     free(tidx);
     free(tdist);
+    free(sidx);
+    free(sdist);
     return 0;
 }

@@ -193,19 +193,20 @@ def bf_match_np(source: np.ndarray, query: np.ndarray, dist_threshold: Optional[
 
 
 def bf_cross_check_np(query: np.ndarray, train: np.ndarray):
+    """crossCheck=True as its documented contract, independently of the C loop: pair (i, j) is returned iff
+    j is i's nearest train row and i is j's nearest query row (first minimum = lowest index on both sides)."""
     q, t = _desc(query), _desc(train)
     n, m = q.shape[0], t.shape[0]
     oi = np.full(n, NO_IDX, np.int32)
     od = np.full(n, NO_DIST, np.int32)
     if n == 0 or m == 0:
         return oi, od
-    d = hamming_matrix_np(t, q)              # [M, N]
-    tq = np.argmin(d, axis=1)                 # first minimum = lowest query index
-    td = d[np.arange(m), tq]
-    for ti in range(m):                       # ascending train rows, strict <
-        if td[ti] < od[tq[ti]]:
-            od[tq[ti]] = td[ti]
-            oi[tq[ti]] = ti
+    d = hamming_matrix_np(q, t)               # [N, M]
+    fwd = np.argmin(d, axis=1)                # query -> nearest train row (lowest index among ties)
+    rev = np.argmin(d, axis=0)                # train -> nearest query row (lowest index among ties)
+    mutual = rev[fwd] == np.arange(n)
+    oi[mutual] = fwd[mutual]
+    od[mutual] = d[np.arange(n), fwd][mutual]
     return oi, od
 
 
@@ -278,3 +279,158 @@ def pose_normal_eq_c(pose12, points, meas, active, fx, fy, cx, cy, huber_delta):
                                            float(huber_delta), _p(H), _p(b), _p(chi2))
     assert rc == 0
     return H, b, chi2
+
+
+# --------------------------------------------------------------------------
+# pose-only Levenberg-Marquardt (Frontend._correct_current_pose) and the Schur reduction of a window BA
+# --------------------------------------------------------------------------
+def se3_exp_np(xi) -> np.ndarray:
+    """exp of the twist [w (rotation), v (translation)] as a 4x4 matrix, by the matrix exponential of its 4x4
+    generator (scipy), i.e. without the closed-form Rodrigues / V-matrix expressions the product code uses."""
+    from scipy.linalg import expm
+
+    w, v = np.asarray(xi[:3], np.float64), np.asarray(xi[3:], np.float64)
+    G = np.zeros((4, 4))
+    G[:3, :3] = [[0.0, -w[2], w[1]], [w[2], 0.0, -w[0]], [-w[1], w[0], 0.0]]
+    G[:3, 3] = v
+    return expm(G)
+
+
+def _huber_rho(chi2: np.ndarray, delta: float) -> float:
+    """g2o RobustKernelHuber::robustify, rho[0] summed: e2 for sqrt(e2) <= delta, 2 delta sqrt(e2) - delta^2 beyond."""
+    if delta <= 0:
+        return float(np.sum(chi2))
+    s = np.sqrt(chi2)
+    return float(np.sum(np.where(s <= delta, chi2, 2.0 * delta * s - delta * delta)))
+
+
+def pose_lm_np(pose, points, meas, fx, fy, cx, cy, rounds: int = 4, iterations: int = 10,
+               chi2_threshold: float = 5.991 ** 2, huber_delta: float = 1.0):
+    """Frontend._correct_current_pose (frontend.py:298-393) on arrays, CPU only.
+
+    Round logic from the reference: `rounds` outer rounds (frontend.py:358), each restarting from the frame's pose
+    (:360) and running optimizer.optimize(10) (:365); after each round every edge is classified by
+    chi2() > 5.991**2 (:356, :371-377: outliers go to level 1 and leave the optimisation, inliers return to level 0),
+    and after round index 2 the robust kernel is removed (:378-379).  The optimiser is g2o's published
+    OptimizationAlgorithmLevenberg: lambda0 = 1e-5 * max diag(H); per iteration up to 10 trials of
+    (H + lambda I) dx = -b; rho = (chi - chi_new) / (dx.(lambda dx - b) + 1e-3); accepted iff rho > 0 and finite:
+    lambda *= max(1/3, min(1 - (2 rho - 1)^3, 2/3)), ni = 2; rejected: lambda *= ni, ni *= 2; an iteration that ends
+    without an accepted step ends the round.  Update convention: the one frontend.py:288-291's Jacobian is the
+    derivative for, T <- exp([w, v]) T (rotation first).  Residuals, Jacobians and Huber weights come from the C oracle
+    (oracle_pose_normal_eq_f64); nothing here touches the HIP library.
+
+    Returns (T 4x4, inliers bool [O], chi2 [O] at T, accepted LM steps)."""
+    P = np.asarray(pose, np.float64)
+    T0 = np.eye(4)
+    T0[:3, :4] = P.reshape(3, 4) if P.size == 12 else P.reshape(-1, 4)[:3, :4]
+    points = np.ascontiguousarray(points, np.float64).reshape(-1, 3)
+    meas = np.ascontiguousarray(meas, np.float64).reshape(-1, 2)
+    O = points.shape[0]
+    active = np.ones(O, bool)
+    delta = float(huber_delta)
+    T, chi2, accepted = T0, np.zeros(O), 0
+
+    def evaluate(Tm):
+        return pose_normal_eq_c(Tm[:3, :4].reshape(12), points, meas, active.astype(np.uint8), fx, fy, cx, cy, delta)
+
+    for rnd in range(rounds):
+        T = T0.copy()
+        H, b, chi2 = evaluate(T)
+        cur = _huber_rho(chi2[active], delta)
+        lam = 1e-5 * max(float(np.max(np.diag(H))), 1e-12)
+        ni = 2.0
+        for _ in range(iterations):
+            if not active.any():
+                break
+            stepped = False
+            for _trial in range(10):
+                try:
+                    dx = np.linalg.solve(H + lam * np.eye(6), -b)
+                except np.linalg.LinAlgError:
+                    lam, ni = lam * ni, ni * 2
+                    continue
+                Tn = se3_exp_np(dx) @ T
+                Hn, bn, chi2n = evaluate(Tn)
+                new = _huber_rho(chi2n[active], delta)
+                rho = (cur - new) / (float(dx @ (lam * dx - b)) + 1e-3)
+                if rho > 0 and np.isfinite(new):
+                    T, H, b, chi2, cur = Tn, Hn, bn, chi2n, new
+                    lam *= max(1.0 / 3.0, min(1.0 - (2.0 * rho - 1.0) ** 3, 2.0 / 3.0))
+                    ni = 2.0
+                    stepped = True
+                    accepted += 1
+                    break
+                lam, ni = lam * ni, ni * 2
+                if not np.isfinite(lam):
+                    break
+            if not stepped:
+                break
+        active = chi2 <= chi2_threshold
+        if rnd == 2:
+            delta = 0.0
+    return T, active, chi2, accepted
+
+
+def ba_schur_np(poses12, points, obs_pose, obs_point, meas, fx, fy, cx, cy, huber_delta: float, lam: float):
+    """Reduced camera system of a window bundle adjustment, observation by observation in f64 on the C oracle's
+    residuals and Jacobians (reproj_rj_c, frontend.py:272-291 + the 2x3 point Jacobian).
+
+    With w = Huber weight, per observation o = (pose k, point l):  Hpp[k] += w Jp^T Jp, bp[k] += w Jp^T e,
+    Hll[l] += w Jq^T Jq, bl[l] += w Jq^T e, Hpl[o] = w Jp^T Jq.  Points are eliminated with damping lam:
+    E[l] = (Hll[l] + lam I)^-1 (identity for points nobody observes),
+    S[k1,k2] = delta(k1,k2) (Hpp[k1] + lam I) - sum_l Hpl[k1,l] E[l] Hpl[k2,l]^T,
+    rhs[k] = -bp[k] + sum_l Hpl[k,l] E[l] bl[l];  cost = sum of Huber rho(e.e).
+    Returns a dict with S [K,K,6,6], rhs [K,6], bp, bl, E, Hpl [O,6,3], cost."""
+    poses12 = np.ascontiguousarray(poses12, np.float64).reshape(-1, 12)
+    points = np.ascontiguousarray(points, np.float64).reshape(-1, 3)
+    K, L, O = poses12.shape[0], points.shape[0], len(obs_pose)
+    e, Jp, Jq = reproj_rj_c(poses12, points, obs_pose, obs_point, meas, fx, fy, cx, cy, with_point=True)
+    Hpp, bp = np.zeros((K, 6, 6)), np.zeros((K, 6))
+    Hll, bl = np.zeros((L, 3, 3)), np.zeros((L, 3))
+    Hpl = np.zeros((O, 6, 3))
+    cost = 0.0
+    for o in range(O):
+        k, l = int(obs_pose[o]), int(obs_point[o])
+        c2 = float(e[o] @ e[o])
+        s = np.sqrt(c2)
+        w = 1.0
+        if huber_delta > 0 and s > huber_delta:
+            w = huber_delta / s
+            cost += 2.0 * huber_delta * s - huber_delta * huber_delta
+        else:
+            cost += c2
+        Hpp[k] += w * Jp[o].T @ Jp[o]
+        bp[k] += w * Jp[o].T @ e[o]
+        Hll[l] += w * Jq[o].T @ Jq[o]
+        bl[l] += w * Jq[o].T @ e[o]
+        Hpl[o] = w * Jp[o].T @ Jq[o]
+    seen = np.zeros(L, bool)
+    seen[np.asarray(obs_point, np.int64)] = True
+    E = np.zeros((L, 3, 3))
+    for l in range(L):
+        E[l] = np.linalg.inv(Hll[l] + lam * np.eye(3)) if seen[l] else np.eye(3)
+    S = np.zeros((K, K, 6, 6))
+    rhs = -bp.copy()
+    for k in range(K):
+        S[k, k] = Hpp[k] + lam * np.eye(6)
+    by_point = [[] for _ in range(L)]
+    for o in range(O):
+        by_point[int(obs_point[o])].append(o)
+    for l in range(L):
+        for o1 in by_point[l]:
+            Y = Hpl[o1] @ E[l]
+            rhs[int(obs_pose[o1])] += Y @ bl[l]
+            for o2 in by_point[l]:
+                S[int(obs_pose[o1]), int(obs_pose[o2])] -= Y @ Hpl[o2].T
+    return {"S": S, "rhs": rhs, "bp": bp, "bl": bl, "E": E, "Hpl": Hpl, "cost": cost, "seen": seen}
+
+
+def ba_backsub_np(red: dict, obs_pose, obs_point, dp) -> np.ndarray:
+    """Point updates after the pose solve: dl[l] = E[l] (-bl[l] - sum_k Hpl[k,l]^T dp[k]); zero for unseen points."""
+    dp = np.asarray(dp, np.float64).reshape(-1, 6)
+    tmp = -red["bl"].copy()
+    for o in range(len(obs_pose)):
+        tmp[int(obs_point[o])] -= red["Hpl"][o].T @ dp[int(obs_pose[o])]
+    dl = np.einsum("lab,lb->la", red["E"], tmp)
+    dl[~red["seen"]] = 0.0
+    return dl

@@ -141,33 +141,23 @@ extern "C" int slam_bf_match_filter(slam_ctx* ctx, const int32_t* d_idx, const i
 }
 
 // ---- crossCheck ------------------------------------------------------------
-// slot[q] = min over train rows t whose nearest query is q of (dist << 32 | t)
-__global__ __launch_bounds__(256) void cross_init_kernel(unsigned long long* slot, int N) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n < N) slot[n] = ~0ull;
-}
-
-__global__ __launch_bounds__(256) void cross_scatter_kernel(const int2* __restrict__ rev_idx,
-                                                            const int2* __restrict__ rev_dist, int M, int N,
-                                                            unsigned long long* slot) {
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= M) return;
-    const int q = rev_idx[t].x;
-    if (q < 0 || q >= N) return;
-    const unsigned long long key = ((unsigned long long)(unsigned)rev_dist[t].x << 32) | (unsigned)t;
-    atomicMin(&slot[q], key);
-}
-
-__global__ __launch_bounds__(256) void cross_emit_kernel(const unsigned long long* __restrict__ slot, int N,
+// cv2.BFMatcher(normType, crossCheck=True).match: pair (q, t) is returned iff t is q's nearest train row AND q is
+// t's nearest query row (ties to the lowest index on both sides).  OpenCV 4.x batch_distance.cpp gets there by a
+// scatter of the reverse table followed by "if (tidx[sidx[i]] != i) nidx[i] = -1"; whenever that test passes, the
+// scattered row is sidx[i] itself (it has the smallest distance of all train rows and the lowest index among equals),
+// so the scatter is not needed: one gather of the reverse table through the forward one decides each query.
+__global__ __launch_bounds__(256) void cross_emit_kernel(const int2* __restrict__ fwd_idx,
+                                                         const int2* __restrict__ fwd_dist, int N,
+                                                         const int2* __restrict__ rev_idx, int M,
                                                          int* __restrict__ out_idx, int* __restrict__ out_dist,
                                                          filter_scratch* s) {
     const int n = blockIdx.x * 256 + threadIdx.x;
     unsigned int kept = 0;
     if (n < N) {
-        const unsigned long long k = slot[n];
-        const bool has = k != ~0ull;
-        out_idx[n] = has ? (int)(unsigned)k : SLAM_NO_MATCH_IDX;
-        out_dist[n] = has ? (int)(k >> 32) : SLAM_NO_MATCH_DIST;
+        const int t = fwd_idx[n].x;
+        const bool has = t >= 0 && t < M && rev_idx[t].x == n;
+        out_idx[n] = has ? t : SLAM_NO_MATCH_IDX;
+        out_dist[n] = has ? fwd_dist[n].x : SLAM_NO_MATCH_DIST;
         kept = has ? 1u : 0u;
     }
 #pragma unroll
@@ -175,33 +165,28 @@ __global__ __launch_bounds__(256) void cross_emit_kernel(const unsigned long lon
     if ((threadIdx.x & 63) == 0 && kept) atomicAdd(&s->count, (unsigned long long)kept);
 }
 
-int slam_cross_launch(slam_ctx* ctx, const int32_t* d_rev_idx, const int32_t* d_rev_dist, int64_t M, int64_t N,
-                      int32_t* d_out_idx, int32_t* d_out_dist) {
+int slam_cross_launch(slam_ctx* ctx, const int32_t* d_fwd_idx, const int32_t* d_fwd_dist, int64_t N,
+                      const int32_t* d_rev_idx, int64_t M, int32_t* d_out_idx, int32_t* d_out_dist) {
     filter_scratch* s = nullptr;
     if (int rc = filter_scratch_ptr(ctx, &s)) return rc;
-    void* ws = nullptr;
-    if (int rc = slam_workspace(ctx, (uint64_t)N * 8, &ws)) return rc;
-    unsigned long long* slot = (unsigned long long*)ws;
     filter_init_kernel<<<1, 1, 0, ctx->stream>>>(s);
-    cross_init_kernel<<<(unsigned)((N + 255) / 256), 256, 0, ctx->stream>>>(slot, (int)N);
-    if (M)
-        cross_scatter_kernel<<<(unsigned)((M + 255) / 256), 256, 0, ctx->stream>>>(
-            (const int2*)d_rev_idx, (const int2*)d_rev_dist, (int)M, (int)N, slot);
-    cross_emit_kernel<<<(unsigned)((N + 255) / 256), 256, 0, ctx->stream>>>(slot, (int)N, d_out_idx, d_out_dist, s);
+    cross_emit_kernel<<<(unsigned)((N + 255) / 256), 256, 0, ctx->stream>>>(
+        (const int2*)d_fwd_idx, (const int2*)d_fwd_dist, (int)N, (const int2*)d_rev_idx, (int)M, d_out_idx, d_out_dist, s);
     SLAM_HIP(hipGetLastError());
     return SLAM_OK;
 }
 
-extern "C" int slam_bf_cross_check(slam_ctx* ctx, const int32_t* d_rev_idx, const int32_t* d_rev_dist, int64_t M,
-                                   int64_t N, int32_t* d_out_idx, int32_t* d_out_dist, int64_t* h_count) {
+extern "C" int slam_bf_cross_check(slam_ctx* ctx, const int32_t* d_fwd_idx, const int32_t* d_fwd_dist, int64_t N,
+                                   const int32_t* d_rev_idx, int64_t M, int32_t* d_out_idx, int32_t* d_out_dist,
+                                   int64_t* h_count) {
     SLAM_REQUIRE(ctx, "slam_bf_cross_check: null ctx");
     SLAM_REQUIRE(N >= 0 && M >= 0 && N <= (1ll << 30) && M <= (1ll << 30), "bad sizes");
     if (h_count) *h_count = 0;
     if (N == 0) return SLAM_OK;
-    SLAM_REQUIRE(d_out_idx && d_out_dist && (M == 0 || (d_rev_idx && d_rev_dist)),
+    SLAM_REQUIRE(d_out_idx && d_out_dist && d_fwd_idx && d_fwd_dist && (M == 0 || d_rev_idx),
                  "slam_bf_cross_check: null device pointer");
     SLAM_HIP(hipSetDevice(ctx->device));
-    if (int rc = slam_cross_launch(ctx, d_rev_idx, d_rev_dist, M, N, d_out_idx, d_out_dist)) return rc;
+    if (int rc = slam_cross_launch(ctx, d_fwd_idx, d_fwd_dist, N, d_rev_idx, M, d_out_idx, d_out_dist)) return rc;
     filter_scratch h;
     SLAM_HIP(hipMemcpyAsync(&h, ctx->scratch, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
     SLAM_HIP(hipStreamSynchronize(ctx->stream));

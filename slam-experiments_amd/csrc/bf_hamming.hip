@@ -22,11 +22,16 @@
 //     lexicographically.
 //   * the train axis is split into chunks (grid.y) so any N fills 256 CUs and
 //     finished waves are replaced until the end (a lone wave per SIMD issues at
-//     under half rate).  Blocks that scan different chunks for the same queries
-//     exchange their 2nd-best distance through a per-query bound in global
-//     memory (atomicMin + relaxed agent-scope load per tile, more often in a
-//     block's first tile), so a chunk does not start from an infinite
-//     threshold; a stale bound is only looser, never wrong.
+//     under half rate).  Chunk boundaries come from a small table built on the
+//     host: a few short LEADER chunks first, then uniform ones, then a run of
+//     shrinking ones so that the blocks dispatched last have the least to do.
+//     Blocks that scan different chunks for the same queries exchange their
+//     2nd-best distance through a per-query bound in global memory (atomicMin +
+//     relaxed agent-scope load per tile, more often in a block's first tile), so
+//     a chunk does not start from an infinite threshold; a stale bound is only
+//     looser, never wrong.  The leader blocks (lowest grid.y, dispatched first)
+//     run at raised wave priority and publish the exact 2nd-best distance over
+//     their rows, so the rest of the grid gets a tight bound early.
 //   * every block folds its top-2 into a per-query 64-bit slot with a CAS loop;
 //     the last block to arrive for a query block (agent-scope ticket) decodes
 //     the slots to (int32 idx, int32 dist) and restores the merge state, so a
@@ -37,6 +42,7 @@
 // 4-cycle op, which is why train rows come from LDS into VGPRs.
 #include "internal.h"
 #include <stdio.h>
+#include <vector>
 
 typedef uint32_t u32;
 
@@ -142,35 +148,46 @@ struct bf_state {
     u32* arrivals;              // [query blocks]  how many chunk blocks have merged their result
 };
 
-// fold this block's (b1, b2) into best[q]: lock-free CAS loop, keys of different chunks are distinct
-__device__ __forceinline__ void merge_into_slot(unsigned long long* slot, u32 b1, u32 b2) {
-    if (b1 == SLAM_KEY_NONE) return;
+// fold this block's (b1, b2) into best[q]: lock-free CAS loop, keys of different chunks are distinct.
+// Returns the 2nd key of the merged slot as this thread saw it (an upper bound of the final one).
+__device__ __forceinline__ u32 merge_into_slot(unsigned long long* slot, u32 b1, u32 b2) {
     unsigned long long old = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (b1 == SLAM_KEY_NONE) return (u32)old;
     while (true) {
         const u32 o1 = (u32)(old >> 32), o2 = (u32)old;
         const u32 k1 = min(o1, b1);
         const u32 k2 = min(max(o1, b1), min(o2, b2));
         const unsigned long long merged = ((unsigned long long)k1 << 32) | k2;
-        if (merged == old) return;
+        if (merged == old) return k2;
         const unsigned long long prev = atomicCAS(slot, old, merged);
-        if (prev == old) return;
+        if (prev == old) return k2;
         old = prev;
     }
 }
 
-// grid.x = query blocks of 256*R rows, grid.y = train chunks of `chunk` rows.  Every block merges
-// its top-2 into st.best; the last block to arrive for a query block decodes (idx + train_base, dist).
+// grid.x = query blocks of 256*R rows, grid.y = train chunks: block (x, y) scans rows [tbl[y], tbl[y+1]).  Every block
+// merges its top-2 into st.best; the last block to arrive for a query block decodes (idx + train_base, dist) and
+// restores the merge state.  Blocks with y < lead are the leaders: raised wave priority (VALU issue is arbitrated by
+// priority, then age), and after their merge they publish the exact 2nd-best distance of everything merged so far.
+// Nobody waits for them: the other blocks pick the bound up at their next share point.  (Holding the other blocks
+// back until their leaders are done was measured and lost 15-20 %: the leaders alone cannot keep the SIMDs busy.)
 template <int R>
 __global__ __launch_bounds__(256) void bf_top2_kernel(const uint4* __restrict__ q, int N,
-                                                      const uint4* __restrict__ t, int M, int chunk,
-                                                      bf_state st, int train_base, int2* __restrict__ out_idx,
-                                                      int2* __restrict__ out_dist) {
+                                                      const uint4* __restrict__ t, const int* __restrict__ tbl,
+                                                      int lead, int lead_prio, bf_state st, int train_base,
+                                                      int2* __restrict__ out_idx, int2* __restrict__ out_dist) {
     __shared__ uint4 tile[2][SLAM_TILE_ROWS * 2];
     __shared__ u32 s_last;
     u32* __restrict__ bound = st.bound;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int qbase = blockIdx.x * (256 * R) + wave * (64 * R) + lane;
+    const bool leader = (int)blockIdx.y < lead;
+    if (leader) {                       // s_setprio takes an immediate
+        if (lead_prio == 3) __builtin_amdgcn_s_setprio(3);
+        else if (lead_prio == 2) __builtin_amdgcn_s_setprio(2);
+        else if (lead_prio == 1) __builtin_amdgcn_s_setprio(1);
+    }
 
     u32 qr[R][8];
 #pragma unroll
@@ -189,8 +206,8 @@ __global__ __launch_bounds__(256) void bf_top2_kernel(const uint4* __restrict__ 
         init[r] = SLAM_ACC_BIAS - (SLAM_KEY_NONE >> SLAM_KEY_IDX_BITS);  // "distance 511": everything enters
     }
 
-    const int t0 = blockIdx.y * chunk;
-    const int t1 = min(M, t0 + chunk);
+    const int t0 = tbl[blockIdx.y];
+    const int t1 = tbl[blockIdx.y + 1];
 
     // prologue: first tile -> LDS buffer 0
 #pragma unroll
@@ -267,7 +284,11 @@ __global__ __launch_bounds__(256) void bf_top2_kernel(const uint4* __restrict__ 
             // bound[q] >= the final 2nd-best distance: a block whose best row is already farther than that
             // cannot contribute, so most chunk blocks skip the CAS (one 4-byte load instead)
             const u32 g = __hip_atomic_load(&st.bound[qi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((b1[r] >> SLAM_KEY_IDX_BITS) <= g) merge_into_slot(&st.best[qi], b1[r], b2[r]);
+            if ((b1[r] >> SLAM_KEY_IDX_BITS) <= g) {
+                const u32 k2 = merge_into_slot(&st.best[qi], b1[r], b2[r]);
+                // leaders leave the exact 2nd-best distance of everything merged so far as the bound
+                if (leader && (k2 >> SLAM_KEY_IDX_BITS) < g) atomicMin(&st.bound[qi], k2 >> SLAM_KEY_IDX_BITS);
+            }
         }
     }
     // Arrival ticket (cdna_hip_programming.md G16, counter form): the merges above are returning
@@ -345,26 +366,35 @@ __global__ __launch_bounds__(256) void bf_fill_none_kernel(int N, int2* __restri
 // ---- host side -----------------------------------------------------------
 
 struct bf_plan {
-    int R;        // queries per lane
-    int qblocks;  // grid.x
-    int chunk;    // train rows per chunk (a multiple of the LDS tile, or of 32 rows for frame-sized inputs)
-    int S;        // grid.y
+    int R;           // queries per lane
+    int qblocks;     // grid.x
+    int S;           // grid.y = number of chunks (entries of the boundary table - 1)
+    int chunk;       // rows of a uniform chunk (a multiple of the LDS tile, or of 32 rows for frame-sized inputs)
+    int lead;        // leader chunks (the first `lead` entries of the table)
+    int lead_rows;   // rows they cover together
+    int tail;        // shrinking chunks at the end of the table
+    int lead_prio;   // s_setprio level of the leader blocks (0 = none)
 };
 
-// tuning overrides (0 = heuristic); set through slam_bf_set_tuning
-static int g_force_R = 0;
-static int g_blocks_per_cu = 0;
-
-extern "C" int slam_bf_set_tuning(int R, int blocks_per_cu) {
-    SLAM_REQUIRE(R == 0 || R == 1 || R == 2 || R == 4 || R == 8, "R must be 0, 1, 2, 4 or 8");
-    SLAM_REQUIRE(blocks_per_cu >= 0 && blocks_per_cu <= 64, "blocks_per_cu out of range");
-    g_force_R = R;
-    g_blocks_per_cu = blocks_per_cu;
+// Tuning overrides live in the context (0 = heuristic): set through slam_bf_set_tuning, read under ctx->mu.
+extern "C" int slam_bf_set_tuning(slam_ctx* ctx, const int32_t* h_knobs, int count) {
+    SLAM_REQUIRE(ctx, "slam_bf_set_tuning: null ctx");
+    SLAM_REQUIRE(count >= 0 && count <= SLAM_BF_KNOBS && (h_knobs || count == 0), "bad knob array");
+    int k[SLAM_BF_KNOBS] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < count; i++) k[i] = h_knobs[i];
+    SLAM_REQUIRE(k[0] == 0 || k[0] == 1 || k[0] == 2 || k[0] == 4 || k[0] == 8, "R must be 0, 1, 2, 4 or 8");
+    SLAM_REQUIRE(k[1] >= 0 && k[1] <= 64, "blocks_per_cu out of range");
+    SLAM_REQUIRE(k[2] >= -1 && k[2] <= (1 << 22), "lead_rows out of range");
+    SLAM_REQUIRE(k[3] >= 0 && k[3] <= (1 << 22) && k[3] % 32 == 0, "lead_chunk must be a multiple of 32 rows");
+    SLAM_REQUIRE(k[4] >= -1 && k[4] <= 3, "lead_prio must be -1 (no raise), 0 (shipped) or 1..3");
+    SLAM_REQUIRE(k[5] >= -1 && k[5] <= 4096, "tail out of range");
+    std::lock_guard<std::mutex> g(ctx->mu);
+    for (int i = 0; i < SLAM_BF_KNOBS; i++) ctx->bf_knob[i] = k[i];
     return SLAM_OK;
 }
 
-// chunks for a given R: aim at `blocks_per_cu` blocks per CU, a chunk being at least one LDS tile
-static void plan_for(const slam_ctx* ctx, int64_t N, int64_t M, int R, int blocks_per_cu, bf_plan* p) {
+// uniform chunks of the rows [0, M) for a given R: aim at `blocks_per_cu` blocks per CU, a chunk being at least one LDS tile
+static void plan_uniform(const slam_ctx* ctx, int64_t N, int64_t M, int R, int blocks_per_cu, bool forced, bf_plan* p) {
     const int64_t tiles = (M + SLAM_TILE_ROWS - 1) / SLAM_TILE_ROWS;
     p->R = R;
     p->qblocks = (int)((N + 256 * R - 1) / (256 * R));
@@ -381,25 +411,114 @@ static void plan_for(const slam_ctx* ctx, int64_t N, int64_t M, int R, int block
     // latency-bound on one block's serial scan: cut the train rows into sub-tile chunks, one block per CU.
     // Measured: 200 x 200 21.6 -> 9.1 us, 1000 x 1000 27.1 -> 12.7 us, 2000 x 2000 28.5 -> 19.5 us; from
     // 4096 x 4096 up finer chunks only add cold starts and merges (34 -> 46-91 us), so those keep whole tiles.
-    if (!g_blocks_per_cu && (int64_t)p->qblocks * tiles < ctx->num_cu) {
+    if (!forced && (int64_t)p->qblocks * tiles < ctx->num_cu) {
         int64_t want = ctx->num_cu / p->qblocks;
         int64_t c2 = (M + want - 1) / want;
         c2 = (c2 + 31) / 32 * 32;
         if (c2 < chunk) chunk = c2;
     }
     p->chunk = (int)chunk;
-    p->S = (int)((M + chunk - 1) / chunk);
 }
 
-static bf_plan make_plan(const slam_ctx* ctx, int64_t N, int64_t M) {
+// The chunk boundary table for N x M (tbl[0] = 0 ... tbl[S] = M) and the plan that goes with it.
+//   leaders:  `lead` chunks covering the first lead_rows rows; they run at raised priority and publish exact bounds.
+//             The 2nd-best distance over s rows is the 2/s quantile of a query's distances and a wave takes the update
+//             path for a row when any of its 64 lanes beats its threshold, so a block starting from the bound of s
+//             rows fires on about 128/s of its first rows.
+//   uniform:  chunks of p.chunk rows.
+//   tail:     the last `tail` chunks shrink linearly, so the blocks dispatched last (the youngest waves, which the
+//             age-ordered VALU arbiter serves last) have the least left to do when the grid drains.
+static bf_plan make_plan(slam_ctx* ctx, int64_t N, int64_t M, std::vector<int>* tbl) {
+    std::lock_guard<std::mutex> g(ctx->mu);
+    const int* k = ctx->bf_knob;
     bf_plan p;
     // R = 1 query per lane measured fastest at every size tried (64k x 64k: 1.68 ms vs 1.79 ms for R = 2,
     // 1.96 ms for R = 4; 58 VGPRs, 8 waves/SIMD); R = 2 / 4 / 8 stay available through slam_bf_set_tuning.
-    plan_for(ctx, N, M, g_force_R ? g_force_R : 1, g_blocks_per_cu, &p);
+    plan_uniform(ctx, N, M, k[0] ? k[0] : 1, k[1], k[1] != 0, &p);
+    const int64_t slots = (int64_t)ctx->num_cu * 8;                      // resident blocks of 4 waves at 8 waves/SIMD
+    // ---- leaders
+    int64_t lead_rows = k[2] < 0 ? 0 : k[2];
+    if (k[2] == 0 && M >= 16384) {
+        lead_rows = M / 16;
+        if (lead_rows > 4096) lead_rows = 4096;
+    }
+    lead_rows = lead_rows / 32 * 32;
+    if (lead_rows + p.chunk > M) lead_rows = 0;                          // leave the rest of the grid real work
+    int64_t lead_chunk = k[3];
+    if (lead_rows && !lead_chunk) {
+        // about one leader wave per SIMD (one block per CU) across all query blocks, chunks of at least 128 rows
+        int64_t per_q = (ctx->num_cu + p.qblocks - 1) / p.qblocks;
+        if (per_q > lead_rows / 128) per_q = lead_rows / 128;
+        if (per_q < 1) per_q = 1;
+        lead_chunk = (lead_rows / per_q + 31) / 32 * 32;
+    }
+    p.lead = lead_rows ? (int)((lead_rows + lead_chunk - 1) / lead_chunk) : 0;
+    p.lead_rows = (int)lead_rows;
+    p.lead_prio = k[4] < 0 ? 0 : (k[4] ? k[4] : 3);
+    // ---- tail
+    const int64_t rest = M - lead_rows;
+    int64_t n_uniform = (rest + p.chunk - 1) / p.chunk;
+    int64_t tail = k[5] < 0 ? 0 : k[5];
+    if (k[5] == 0) tail = 0;                                             // shipped choice
+    if (tail > 0) {
+        const int64_t last_round = (slots + p.qblocks - 1) / p.qblocks;  // chunk indices in flight when the grid drains
+        if (tail > last_round) tail = last_round;
+        if (tail > n_uniform / 2) tail = n_uniform / 2;
+    }
+    std::vector<int>& b = *tbl;
+    b.clear();
+    b.push_back(0);
+    for (int i = 0; i < p.lead; i++) {
+        const int64_t e = (int64_t)(i + 1) * lead_chunk;
+        b.push_back((int)(e < lead_rows ? e : lead_rows));
+    }
+    // sizes of the shrinking chunks: chunk * (tail - i) / (tail + 1), multiples of 32, at least 32 rows
+    std::vector<int> ts;
+    int64_t tail_rows = 0;
+    for (int64_t i = 0; i < tail; i++) {
+        int64_t sz = (int64_t)p.chunk * (tail - i) / (tail + 1) / 32 * 32;
+        if (sz < 32) sz = 32;
+        ts.push_back((int)sz);
+        tail_rows += sz;
+    }
+    if (tail_rows >= rest) { ts.clear(); tail_rows = 0; }
+    int64_t pos = lead_rows;
+    const int64_t uniform_end = M - tail_rows;
+    while (pos < uniform_end) {
+        pos = pos + p.chunk < uniform_end ? pos + p.chunk : uniform_end;
+        b.push_back((int)pos);
+    }
+    for (int sz : ts) {
+        pos += sz;
+        b.push_back((int)pos);
+    }
+    b.back() = (int)M;
+    p.tail = (int)ts.size();
+    p.S = (int)b.size() - 1;
     return p;
 }
 
-// merge state for up to N queries, kept clean between launches (see bf_state)
+extern "C" int slam_bf_plan_info(slam_ctx* ctx, int64_t N, int64_t M, int32_t* h_plan /*[8]*/) {
+    SLAM_REQUIRE(ctx && h_plan, "slam_bf_plan_info: null argument");
+    SLAM_REQUIRE(N >= 1 && M >= 1 && M <= SLAM_MAX_TRAIN_PER_PASS && N <= (1ll << 30), "bad sizes");
+    std::vector<int> tbl;
+    const bf_plan p = make_plan(ctx, N, M, &tbl);
+    h_plan[0] = p.R; h_plan[1] = p.qblocks; h_plan[2] = p.chunk; h_plan[3] = p.S;
+    h_plan[4] = p.lead_rows; h_plan[5] = p.lead; h_plan[6] = p.tail; h_plan[7] = ctx->num_cu;
+    return SLAM_OK;
+}
+
+// merge state for up to N queries, kept clean between launches (see bf_state), followed by the chunk boundary table
+#define SLAM_BF_TBL_MAX 65536   // entries; grid.y <= 65535
+static int bf_state_fill(slam_ctx* ctx) {
+    char* p = (char*)ctx->bf_state_mem;
+    const size_t rows = (size_t)ctx->bf_state_rows, blocks = (rows + 255) / 256;
+    SLAM_HIP(hipMemsetAsync(p, 0xFF, rows * 8, ctx->stream));
+    SLAM_HIP(hipMemsetAsync(p + rows * 8, 0x7F, rows * 4, ctx->stream));
+    SLAM_HIP(hipMemsetAsync(p + rows * 12, 0, blocks * 4, ctx->stream));
+    return SLAM_OK;
+}
+
 static int bf_state_get(slam_ctx* ctx, int64_t N, bf_state* out) {
     std::lock_guard<std::mutex> g(ctx->mu);
     if (N > ctx->bf_state_rows) {
@@ -411,25 +530,58 @@ static int bf_state_get(slam_ctx* ctx, int64_t N, bf_state* out) {
         const size_t blocks = (size_t)(rows + 255) / 256;         // query blocks at R = 1, the finest split
         const size_t bytes = (size_t)rows * 12 + blocks * 4;
         SLAM_HIP(hipMalloc(&ctx->bf_state_mem, bytes));
-        char* p = (char*)ctx->bf_state_mem;
-        SLAM_HIP(hipMemsetAsync(p, 0xFF, (size_t)rows * 8, ctx->stream));
-        SLAM_HIP(hipMemsetAsync(p + (size_t)rows * 8, 0x7F, (size_t)rows * 4, ctx->stream));
-        SLAM_HIP(hipMemsetAsync(p + (size_t)rows * 12, 0, blocks * 4, ctx->stream));
         ctx->bf_state_rows = rows;
+        if (int rc = bf_state_fill(ctx)) return rc;
     }
     char* p = (char*)ctx->bf_state_mem;
+    const size_t rows = (size_t)ctx->bf_state_rows;
     out->best = (unsigned long long*)p;
-    out->bound = (u32*)(p + (size_t)ctx->bf_state_rows * 8);
-    out->arrivals = (u32*)(p + (size_t)ctx->bf_state_rows * 12);
+    out->bound = (u32*)(p + rows * 8);
+    out->arrivals = (u32*)(p + rows * 12);
     return SLAM_OK;
+}
+
+// the boundary table on the device: re-uploaded only when it differs from the one the last search used
+static int bf_table_get(slam_ctx* ctx, const std::vector<int>& tbl, const int** d_tbl) {
+    std::lock_guard<std::mutex> g(ctx->mu);
+    SLAM_REQUIRE(tbl.size() <= SLAM_BF_TBL_MAX, "train set needs %zu chunks, more than one launch can index", tbl.size() - 1);
+    if (!ctx->bf_tbl_dev) {
+        SLAM_HIP(hipMalloc(&ctx->bf_tbl_dev, SLAM_BF_TBL_MAX * sizeof(int)));
+        SLAM_HIP(hipHostMalloc(&ctx->bf_tbl_host, SLAM_BF_TBL_MAX * sizeof(int), hipHostMallocDefault));
+        ctx->bf_tbl_n = 0;
+    }
+    int* host = (int*)ctx->bf_tbl_host;
+    if (ctx->bf_tbl_n != (int)tbl.size() || memcmp(host, tbl.data(), tbl.size() * sizeof(int)) != 0) {
+        // the previous table may still be read by a queued launch, and the staging copy by a queued upload
+        SLAM_HIP(hipStreamSynchronize(ctx->stream));
+        memcpy(host, tbl.data(), tbl.size() * sizeof(int));
+        ctx->bf_tbl_n = (int)tbl.size();
+        SLAM_HIP(hipMemcpyAsync(ctx->bf_tbl_dev, host, tbl.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    }
+    *d_tbl = (const int*)ctx->bf_tbl_dev;
+    return SLAM_OK;
+}
+
+// Put the merge state back to its idle values (best = none, bound = loose, arrivals = 0).  The kernel restores
+// it itself at the end of every search; this is for the case where one did not finish (a failed launch, a device
+// error reported by a later call): stream-ordered, so it may be issued right behind whatever is still queued.
+extern "C" int slam_bf_reset_state(slam_ctx* ctx) {
+    SLAM_REQUIRE(ctx, "slam_bf_reset_state: null ctx");
+    SLAM_HIP(hipSetDevice(ctx->device));
+    std::lock_guard<std::mutex> g(ctx->mu);
+    if (!ctx->bf_state_mem) return SLAM_OK;
+    return bf_state_fill(ctx);
 }
 
 // one pass over at most 2^23 train rows
 static int bf_pass(slam_ctx* ctx, const void* d_query, int64_t N, const void* d_train, int64_t M,
                    int64_t train_base, int32_t* d_idx, int32_t* d_dist) {
-    const bf_plan p = make_plan(ctx, N, M);
+    std::vector<int> tbl;
+    const bf_plan p = make_plan(ctx, N, M, &tbl);
     bf_state st;
     if (int rc = bf_state_get(ctx, N, &st)) return rc;
+    const int* d_tbl = nullptr;
+    if (int rc = bf_table_get(ctx, tbl, &d_tbl)) return rc;
     const dim3 grid(p.qblocks, p.S), block(256);
     const uint4* q = (const uint4*)d_query;
     const uint4* t = (const uint4*)d_train;
@@ -439,13 +591,17 @@ static int bf_pass(slam_ctx* ctx, const void* d_query, int64_t N, const void* d_
     SLAM_HIP(hipGetLastError());
     if (int rc = slam_prof_begin(ctx)) return rc;
     switch (p.R) {
-        case 8: bf_top2_kernel<8><<<grid, block, 0, ctx->stream>>>(q, (int)N, t, (int)M, p.chunk, st, tb, oi, od); break;
-        case 4: bf_top2_kernel<4><<<grid, block, 0, ctx->stream>>>(q, (int)N, t, (int)M, p.chunk, st, tb, oi, od); break;
-        case 2: bf_top2_kernel<2><<<grid, block, 0, ctx->stream>>>(q, (int)N, t, (int)M, p.chunk, st, tb, oi, od); break;
-        default: bf_top2_kernel<1><<<grid, block, 0, ctx->stream>>>(q, (int)N, t, (int)M, p.chunk, st, tb, oi, od); break;
+        case 8: bf_top2_kernel<8><<<grid, block, 0, ctx->stream>>>(q, (int)N, t, d_tbl, p.lead, p.lead_prio, st, tb, oi, od); break;
+        case 4: bf_top2_kernel<4><<<grid, block, 0, ctx->stream>>>(q, (int)N, t, d_tbl, p.lead, p.lead_prio, st, tb, oi, od); break;
+        case 2: bf_top2_kernel<2><<<grid, block, 0, ctx->stream>>>(q, (int)N, t, d_tbl, p.lead, p.lead_prio, st, tb, oi, od); break;
+        default: bf_top2_kernel<1><<<grid, block, 0, ctx->stream>>>(q, (int)N, t, d_tbl, p.lead, p.lead_prio, st, tb, oi, od); break;
     }
     if (int rc = slam_prof_end(ctx)) return rc;
-    SLAM_HIP(hipGetLastError());
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        (void)slam_bf_reset_state(ctx);
+        return slam_set_error(SLAM_ERR_HIP, "top-2 kernel launch failed: %s", hipGetErrorString(e));
+    }
     return SLAM_OK;
 }
 

@@ -1,6 +1,7 @@
 // ctx.hip — context, device memory, error reporting and stream timers of
 // libslamhip.so.  One slam_ctx = one HIP device + one stream; nothing global
-// is mutable except the thread-local error string (SURVEY.md §8b threading).
+// is mutable except the thread-local error string (SURVEY.md §8b threading);
+// tuning overrides and all scratch state live in the context.
 #include "internal.h"
 #include <stdio.h>
 #include <string.h>
@@ -72,6 +73,8 @@ extern "C" int slam_ctx_destroy(slam_ctx* ctx) {
     if (ctx->io_dev) (void)hipFree(ctx->io_dev);
     if (ctx->io_host) (void)hipHostFree(ctx->io_host);
     if (ctx->bf_state_mem) (void)hipFree(ctx->bf_state_mem);
+    if (ctx->bf_tbl_dev) (void)hipFree(ctx->bf_tbl_dev);
+    if (ctx->bf_tbl_host) (void)hipHostFree(ctx->bf_tbl_host);
     if (ctx->prof_ev) {
         for (int i = 0; i < 2 * slam_ctx::PROF_MAX; i++) (void)hipEventDestroy(ctx->prof_ev[i]);
         delete[] ctx->prof_ev;
@@ -194,6 +197,14 @@ int slam_io_arena(slam_ctx* ctx, uint64_t dev_bytes, uint64_t host_bytes, void**
     }
     *dev = ctx->io_dev;
     *host = ctx->io_host;
+    return SLAM_OK;
+}
+
+extern "C" int slam_io_counters(slam_ctx* ctx, uint64_t* h2d_bytes, uint64_t* d2h_bytes) {
+    SLAM_REQUIRE(ctx, "slam_io_counters: null ctx");
+    std::lock_guard<std::mutex> lk(ctx->io_mu);
+    if (h2d_bytes) *h2d_bytes = ctx->io_h2d_bytes;
+    if (d2h_bytes) *d2h_bytes = ctx->io_d2h_bytes;
     return SLAM_OK;
 }
 

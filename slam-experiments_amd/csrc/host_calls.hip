@@ -36,6 +36,8 @@ extern "C" int slam_bf_knn2_u256_host(slam_ctx* ctx, const uint8_t* h_query, int
     uint8_t* db = (uint8_t*)dev;
     memcpy(hb, h_query, qbytes);
     if (tbytes) memcpy(hb + off_t, h_train, tbytes);
+    ctx->io_h2d_bytes += qbytes + tbytes;
+    ctx->io_d2h_bytes += (uint64_t)N * 16;
     if (zero_copy(N, M)) {
         // frame-sized: the kernels read the pinned block and write the result into it over PCIe themselves
         if (int rc = slam_bf_knn2_u256(ctx, hb, N, hb + off_t, M, 0, (int32_t*)(hb + off_i), (int32_t*)(hb + off_d))) return rc;
@@ -68,23 +70,26 @@ extern "C" int slam_bf_match_host(slam_ctx* ctx, const uint8_t* h_query, int64_t
     if (N == 0 || M == 0) {
         // nothing to report (OpenCV: no candidate -> no match); still hand the query rows over if asked to
         if (N && d_query_keep) {
+            ctx->io_h2d_bytes += qbytes;
             SLAM_HIP(hipMemcpyAsync(d_query_keep, h_query, qbytes, hipMemcpyHostToDevice, ctx->stream));
             SLAM_HIP(hipStreamSynchronize(ctx->stream));
         }
         return SLAM_OK;
     }
     // device arena: [query | train | idx int32[N,2] | dist int32[N,2] | keep u8[N]]; staging mirrors it
-    // (crossCheck, mode 3: | reverse tables int32[M,2] x 2 | idx int32[N] | dist int32[N])
+    // (crossCheck, mode 3: ... | dist int32[N,2] | reverse tables int32[M,2] x 2 | idx int32[N] | dist int32[N])
     const uint64_t off_t = align_up(qbytes, 256), off_i = off_t + align_up(tbytes, 256);
     const uint64_t off_d = off_i + (uint64_t)N * 8, off_k = off_d + (uint64_t)N * 8;
-    const uint64_t total = mode == 3 ? align_up(off_i + (uint64_t)M * 16, 256) + align_up((uint64_t)N * 8, 256)
-                                     : align_up(off_k + N, 256);
+    const uint64_t off_r = align_up(off_k, 256), off_o = align_up(off_r + (uint64_t)M * 16, 256);
+    const uint64_t total = mode == 3 ? align_up(off_o + (uint64_t)N * 8, 256) : align_up(off_k + N, 256);
     void *dev = nullptr, *host = nullptr;
     if (int rc = slam_io_arena(ctx, total, total, &dev, &host)) return rc;
     uint8_t* hb = (uint8_t*)host;
     uint8_t* db = (uint8_t*)dev;
     memcpy(hb, h_query, qbytes);
     if (tbytes) memcpy(hb + off_t, h_train, tbytes);
+    ctx->io_h2d_bytes += qbytes + tbytes;                      // a train side passed as d_train crosses nothing
+    ctx->io_d2h_bytes += mode == 3 ? (uint64_t)N * 8 : (uint64_t)N * 17;
     // frame-sized calls skip the copies: the kernels read the pinned block and write the result into it directly
     const bool zc = zero_copy(N, M);
     uint8_t* io = zc ? hb : db;
@@ -99,15 +104,17 @@ extern "C" int slam_bf_match_host(slam_ctx* ctx, const uint8_t* h_query, int64_t
     }
     const void* dt = h_train ? (const void*)(io + off_t) : d_train;
     if (mode == 3) {
-        // cv2.BFMatcher(crossCheck=True).match: the reverse search (train rows as queries) stays on the device,
-        // only the per-query (idx, dist) pair comes back
-        int32_t* rev_idx = (int32_t*)(db + off_i);
-        int32_t* rev_dist = (int32_t*)(db + off_i + (uint64_t)M * 8);
-        const uint64_t off_o = align_up(off_i + (uint64_t)M * 16, 256);
+        // cv2.BFMatcher(crossCheck=True).match: the forward and the reverse search (train rows as queries) stay on
+        // the device, only the per-query (idx, dist) pair of the mutual nearest neighbours comes back
+        int32_t* fwd_idx = (int32_t*)(db + off_i);
+        int32_t* fwd_dist = (int32_t*)(db + off_d);
+        int32_t* rev_idx = (int32_t*)(db + off_r);
+        int32_t* rev_dist = (int32_t*)(db + off_r + (uint64_t)M * 8);
         int32_t* o_idx = (int32_t*)(io + off_o);
         int32_t* o_dist = (int32_t*)(io + off_o + (uint64_t)N * 4);
+        if (int rc = slam_bf_knn2_u256(ctx, dq, N, dt, M, 0, fwd_idx, fwd_dist)) return rc;
         if (int rc = slam_bf_knn2_u256(ctx, dt, M, dq, N, 0, rev_idx, rev_dist)) return rc;
-        if (int rc = slam_cross_launch(ctx, rev_idx, rev_dist, M, N, o_idx, o_dist)) return rc;
+        if (int rc = slam_cross_launch(ctx, fwd_idx, fwd_dist, N, rev_idx, M, o_idx, o_dist)) return rc;
         if (!zc) SLAM_HIP(hipMemcpyAsync(hb + off_o, db + off_o, (uint64_t)N * 8, hipMemcpyDeviceToHost, ctx->stream));
         SLAM_HIP(hipStreamSynchronize(ctx->stream));
         const int32_t* ri = (const int32_t*)(hb + off_o);
@@ -170,6 +177,8 @@ extern "C" int slam_pose_optimize_host_f64(slam_ctx* ctx, const double* h_pose_i
         memcpy(hb + off_p, h_points, 24 * o);
         memcpy(hb + off_m, h_meas, 16 * o);
     }
+    ctx->io_h2d_bytes += off_m + 16 * o;
+    ctx->io_d2h_bytes += out_inl + o - out_pose;
     SLAM_HIP(hipMemcpyAsync(db, hb, off_m + 16 * o, hipMemcpyHostToDevice, ctx->stream));
     if (int rc = slam_pose_optimize_f64(ctx, (const double*)db, (const double*)(db + off_p), (const double*)(db + off_m),
                                         O, fx, fy, cx, cy, rounds, iterations, chi2_threshold, huber_delta,

@@ -19,12 +19,17 @@ struct slam_ctx {
     int num_cu = 0;
     void* bf_state_mem = nullptr;                   // matcher merge state (best/bound/arrivals), clean between launches
     int64_t bf_state_rows = 0;
+    int bf_knob[SLAM_BF_KNOBS] = {0, 0, 0, 0, 0, 0};   // matcher tuning overrides (slam_bf_set_tuning), 0 = heuristic
+    void* bf_tbl_dev = nullptr;                     // chunk boundary table of the last search (device) ...
+    void* bf_tbl_host = nullptr;                    // ... and its pinned host copy
+    int bf_tbl_n = 0;
     void* scratch = nullptr;                        // 4 KiB device scratch (filter counters, reductions)
     void* io_dev = nullptr;                         // device arena of the host-buffer entry points (grow-only)
     uint64_t io_dev_bytes = 0;
     void* io_host = nullptr;                        // pinned host staging for the same (grow-only)
     uint64_t io_host_bytes = 0;
     std::mutex io_mu;                               // one host-buffer call at a time per context (they share the arena)
+    uint64_t io_h2d_bytes = 0, io_d2h_bytes = 0;    // bytes the host-buffer entry points moved over PCIe (copies and zero-copy), under io_mu
     // profiling of the dominant kernel
     int prof_on = 0;
     static const int PROF_MAX = 4096;
@@ -62,8 +67,8 @@ int slam_io_arena(slam_ctx* ctx, uint64_t dev_bytes, uint64_t host_bytes, void**
 int slam_filter_launch(slam_ctx* ctx, const int32_t* d_idx, const int32_t* d_dist, int64_t N, int mode, double param,
                        uint8_t* d_keep);
 // the crossCheck kernels of slam_bf_cross_check without the read-back (asynchronous on the ctx stream)
-int slam_cross_launch(slam_ctx* ctx, const int32_t* d_rev_idx, const int32_t* d_rev_dist, int64_t M, int64_t N,
-                      int32_t* d_out_idx, int32_t* d_out_dist);
+int slam_cross_launch(slam_ctx* ctx, const int32_t* d_fwd_idx, const int32_t* d_fwd_dist, int64_t N,
+                      const int32_t* d_rev_idx, int64_t M, int32_t* d_out_idx, int32_t* d_out_dist);
 // second stream + hand-off events shared by the RCCL and the peer-copy all-gathers (p2p.hip)
 int slam_second_stream(slam_ctx* ctx);
 void slam_second_stream_destroy(slam_ctx* ctx);

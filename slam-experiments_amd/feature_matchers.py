@@ -9,8 +9,10 @@ CPU fallback — without the library or a gfx950 GPU, ``match`` raises.
 from __future__ import annotations
 
 from abc import ABC, abstractmethod
+from collections.abc import Sequence as _SequenceABC
 from typing import Optional, Sequence
 
+import threading
 from itertools import repeat
 
 import numpy as np
@@ -50,6 +52,44 @@ def _to_dmatches(qi: np.ndarray, ti: np.ndarray, dist: np.ndarray) -> list:
     return list(map(cls, qi.tolist(), ti.tolist(), repeat(0, len(qi)), dist.tolist()))
 
 
+class MatchList(_SequenceABC):
+    """What ``match`` returns: a read-only sequence of ``DMatch`` over the arrays the GPU produced, building the
+    objects only when something looks at them.  The reference's consumers use ``len()`` (the ``< 5`` tracking-loss
+    gates, ``frontend.py:116,163``), iteration and indexing with ``.queryIdx/.trainIdx/.distance``
+    (``frontend.py:174-177,194,205-207``; ``utils.py:14-16,42-44``; ``feature_matchers.py:42-43``): ``len`` costs
+    nothing, the first iteration materialises the whole list once (one constructor call per match), and vectorised
+    callers can read ``queryIdx`` / ``trainIdx`` / ``distance`` as arrays without creating any object.
+    ``cv2.drawMatches`` wants a real list of ``cv2.DMatch``: ``list(matches)`` (``draw_matches`` does that)."""
+
+    __slots__ = ("queryIdx", "trainIdx", "distance", "_objs")
+
+    def __init__(self, qi: np.ndarray, ti: np.ndarray, dist: np.ndarray):
+        self.queryIdx, self.trainIdx, self.distance = qi, ti, dist
+        self._objs = None
+
+    def _all(self) -> list:
+        if self._objs is None:
+            self._objs = _to_dmatches(self.queryIdx, self.trainIdx, self.distance)
+        return self._objs
+
+    def __len__(self) -> int:
+        return len(self.queryIdx)
+
+    def __getitem__(self, i):
+        if self._objs is None and isinstance(i, (int, np.integer)):
+            return _make_dmatch(self.queryIdx[i], self.trainIdx[i], self.distance[i])
+        return self._all()[i]
+
+    def __iter__(self):
+        return iter(self._all())
+
+    def __eq__(self, other):
+        return self._all() == (other._all() if isinstance(other, MatchList) else other)
+
+    def __repr__(self) -> str:
+        return f"MatchList({len(self)} matches)"
+
+
 class FeatureMatcher(ABC):
     @abstractmethod
     def match(self, source_descriptors: np.ndarray, query_descriptors: np.ndarray) -> Sequence[DMatch]:
@@ -62,7 +102,7 @@ class FeatureMatcher(ABC):
             from cv2 import drawMatches, imshow
         except ImportError as exc:
             raise ImportError("draw_matches needs OpenCV (cv2), which is not installed") from exc
-        matches_img = drawMatches(query_img, query_keypoints, source_img, source_keypoints, matches, None)
+        matches_img = drawMatches(query_img, query_keypoints, source_img, source_keypoints, list(matches), None)
         imshow("Matches", matches_img)
 
 
@@ -75,11 +115,21 @@ class BruteForceFeatureMatcher(FeatureMatcher):
                 f"norm_type {norm_type}: only cv2.NORM_HAMMING (6) is implemented (the reference constructs no other, slam.py:24)"
             )
         self.norm_type = int(norm_type)
+        self._cache = None          # slamhip FrameCache, made on the first match(): last frame's rows stay in HBM
+        self._lock = threading.Lock()
 
     def match(self, source_descriptors: np.ndarray, query_descriptors: np.ndarray,
               dist_threshold: Optional[float] = None) -> Sequence[DMatch]:
-        qi, ti, dist = _m.match_arrays(source_descriptors, query_descriptors, dist_threshold)
-        return _to_dmatches(qi, ti, dist)
+        """``bf.match(query, source)`` + the optional min-distance filter (``feature_matchers.py:36-44``).
+
+        The tracking loop calls this with (last frame, current frame) on every frame (``frontend.py:181-187``): the
+        current frame's rows stay on the device, so when they come back as the next call's ``source_descriptors``
+        they are recognised and not uploaded again."""
+        with self._lock:
+            if self._cache is None:
+                self._cache = _m.FrameCache(_m.default_context())
+            qi, ti, dist = _m.match_arrays(source_descriptors, query_descriptors, dist_threshold, cache=self._cache)
+        return MatchList(qi, ti, dist)
 
     # ---- array-level extensions (not in the reference) -----------------------
     def match_arrays(self, source_descriptors, query_descriptors, dist_threshold: Optional[float] = None):

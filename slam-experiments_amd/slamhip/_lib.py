@@ -50,10 +50,12 @@ SIGNATURES = {
     "slam_bf_knn2_u256": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
     "slam_bf_merge_top2": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
     "slam_bf_knn2_u256_host": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p]),
-    "slam_bf_set_tuning": (c_int, [c_int, c_int]),
+    "slam_bf_set_tuning": (c_int, [c_void_p, POINTER(c_int32), c_int]),
+    "slam_bf_plan_info": (c_int, [c_void_p, c_int64, c_int64, POINTER(c_int32)]),
+    "slam_bf_reset_state": (c_int, [c_void_p]),
     "slam_bf_match_filter": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_double, c_void_p,
                                      POINTER(c_int64), POINTER(c_int32)]),
-    "slam_bf_cross_check": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p,
+    "slam_bf_cross_check": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
                                     POINTER(c_int64)]),
     "slam_reproj_rj_f64": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
                                    c_int64, c_double, c_double, c_double, c_double, c_void_p, c_void_p, c_void_p]),
@@ -64,6 +66,7 @@ SIGNATURES = {
                                        c_void_p]),
     "slam_bf_match_host": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_double,
                                    c_void_p, c_void_p, c_void_p, c_void_p]),
+    "slam_io_counters": (c_int, [c_void_p, POINTER(c_uint64), POINTER(c_uint64)]),
     "slam_pose_optimize_host_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double, c_double,
                                             c_double, c_double, c_int, c_int, c_double, c_double, c_void_p, c_void_p,
                                             c_void_p, c_void_p]),

@@ -9,7 +9,7 @@ result, bit-identical to the single-GPU run (no merge step is involved).
 
 The rendezvous (who is rank 0, how the 128-byte RCCL id travels) is the
 launcher's business: ``init_comm`` takes a ``bcast(bytes|None) -> bytes``
-callable, e.g. built on ``torch.distributed`` (gloo) object broadcast.
+callable, e.g. ``slamhip.launch.Rendezvous.bcast`` (standard library only).
 """
 from __future__ import annotations
 
@@ -72,7 +72,7 @@ class PeerMap:
 
     def __init__(self, ctx: Context, rank: int, world: int, buffers, allgather_obj: Callable[[object], list]):
         """``buffers``: this rank's gathered buffers (base allocations); ``allgather_obj(x) -> [x of rank 0, ...]``
-        is the launcher's object all-gather (e.g. ``torch.distributed.all_gather_object`` over gloo)."""
+        is the launcher's object all-gather (e.g. ``slamhip.launch.Rendezvous.allgather``)."""
         self.ctx, self.rank, self.world = ctx, rank, world
         self.ptrs, self.tables = [], []     # [buffer][rank] -> device pointer (0 for this rank); and as ctypes arrays
         mine, failure = [], None
@@ -149,7 +149,8 @@ class _Gathering:
                 self.peers = None
             return False
         # marker round: every rank writes rank+1 into the first bytes of its slot everywhere, then checks all slots
-        mark = np.full(16, self.rank + 1, np.uint8)
+        nmark = min(16, self.slot_bytes)                         # a train-sharded slot is 8 bytes when there is one query
+        mark = np.full(nmark, self.rank + 1, np.uint8)
         for b in range(len(self.gathered)):
             self._slots[b].upload(mark)
             self.peers.push(self._slots[b], self.slot_bytes, b)    # the whole slot: the offset is rank * slot_bytes
@@ -157,7 +158,7 @@ class _Gathering:
         good = True
         for g in self.gathered:
             raw = g.download(np.uint8, (self.world, self.slot_bytes))
-            good = good and all((raw[r, :16] == r + 1).all() for r in range(self.world))
+            good = good and all((raw[r, :nmark] == r + 1).all() for r in range(self.world))
         for g in self.gathered:                                  # back to "no match" everywhere before real passes
             check(self.ctx.lib.slam_memset(self.ctx.handle, g.ptr, 0xFF, g.nbytes))
         self.ctx.sync()
@@ -169,6 +170,27 @@ class _Gathering:
             return False
         self.collective = "p2p"
         return True
+
+
+    def close_peers(self) -> None:
+        """Unmap the peers' buffers (first step of the teardown of the peer-copy tier)."""
+        if self.peers is not None:
+            self.peers.close()
+            self.peers = None
+
+    def _release(self, barrier: Optional[Callable[[], None]], buffers) -> None:
+        """Teardown in the order HIP IPC requires: every rank unmaps what it imported, then ALL ranks meet at the
+        launcher's barrier, and only then does anybody free the allocations it exported - freeing an exported
+        buffer while a peer still has it mapped (or has a copy into it in flight) is undefined behaviour."""
+        self.ctx.sync()
+        if self.peers is not None:
+            if barrier is None:
+                raise RuntimeError("this matcher's buffers are mapped by peer processes: call free(barrier) with the "
+                                   "launcher's barrier (all ranks synced, then a process barrier)")
+            self.close_peers()
+            barrier()
+        for b in buffers:
+            b.free()
 
 
 class ShardedMatcher(_Gathering):
@@ -232,13 +254,9 @@ class ShardedMatcher(_Gathering):
         dist = raw[:, 1].reshape(self.world * per, 2)[:n]
         return np.ascontiguousarray(idx), np.ascontiguousarray(dist)
 
-    def free(self) -> None:
-        self.ctx.sync()
-        if self.peers is not None:
-            self.peers.close()
-            self.peers = None
-        for g in self.gathered:
-            g.free()
+    def free(self, barrier: Optional[Callable[[], None]] = None) -> None:
+        """``barrier`` is required when the peer-copy tier is active (see ``_release``)."""
+        self._release(barrier, self.gathered)
         self.d_query.free()
         self.d_train.free()
 
@@ -288,13 +306,9 @@ class TrainShardedMatcher(_Gathering):
                                        self.out_idx.ptr, self.out_dist.ptr))
         return self.out_idx.download(np.int32, (self.n, 2)), self.out_dist.download(np.int32, (self.n, 2))
 
-    def free(self) -> None:
-        self.ctx.sync()
-        if self.peers is not None:
-            self.peers.close()
-            self.peers = None
-        for b in (*self.gathered, self.out_idx, self.out_dist):
-            b.free()
+    def free(self, barrier: Optional[Callable[[], None]] = None) -> None:
+        """``barrier`` is required when the peer-copy tier is active (see ``_release``)."""
+        self._release(barrier, (*self.gathered, self.out_idx, self.out_dist))
         self.d_query.free()
         self.d_train.free()
 

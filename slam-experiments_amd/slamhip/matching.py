@@ -98,20 +98,6 @@ def knn_match_arrays(query, train, k: int = 2, ctx: Optional[Context] = None) ->
     return np.ascontiguousarray(idx[:, :k]), np.ascontiguousarray(dist[:, :k])
 
 
-def _filter_device(ctx: Context, table: Top2Table, mode: int, param: float) -> Tuple[np.ndarray, int]:
-    keep = ctx.malloc(max(table.rows, 1))
-    cnt = ctypes.c_int64(0)
-    mind = ctypes.c_int32(0)
-    try:
-        check(ctx.lib.slam_bf_match_filter(ctx.handle, table.idx.ptr, table.dist.ptr, table.rows, mode, float(param),
-                                           keep.ptr, ctypes.byref(cnt), ctypes.byref(mind)))
-        k = keep.download(np.uint8, (table.rows,)).astype(bool) if table.rows else np.zeros(0, bool)
-    finally:
-        keep.free()
-    assert int(k.sum()) == cnt.value
-    return k, mind.value
-
-
 def _match_host(ctx: Context, q: np.ndarray, t: Optional[np.ndarray], d_train: Optional[DeviceBuffer], m: int,
                 keep_query: Optional[DeviceBuffer], mode: int, param: float):
     """One ``slam_bf_match_host`` call: upload, top-2 search, selection, download, one synchronisation."""
@@ -129,17 +115,91 @@ def _match_host(ctx: Context, q: np.ndarray, t: Optional[np.ndarray], d_train: O
     return qi[:c], ti[:c], dist[:c]
 
 
-def match_arrays(source, query, dist_threshold: Optional[float] = None, ctx: Optional[Context] = None):
+class FrameCache:
+    """The query rows of a matcher's last call, kept in HBM (SURVEY.md §8f row f2 for unchanged ``slam.py`` users).
+
+    ``Frontend._match_features`` (``frontend.py:181-187``) calls ``match(desc_last, desc_cur)`` on every frame with
+    two fresh numpy copies (``Frame.get_descriptors``, ``primitives.py:200-205``), so the train side of frame k is
+    byte for byte the query side of frame k-1.  The cache keeps that matrix on the device (and its bytes on the host,
+    to recognise it: comparing 6.4 KB costs less than sending them); a call whose source rows equal it passes the
+    device copy as ``d_train`` and uploads only the new query rows, straight into the buffer the next call will search.
+    Two buffers alternate, grown on demand, so a steady stream of frames allocates nothing."""
+
+    MAX_ROWS = 1 << 16      # beyond this the comparison costs as much as the upload: such calls bypass the cache
+
+    def __init__(self, ctx: Context):
+        self.ctx = ctx
+        self._bufs = [None, None]
+        self._cur = 0                       # index of the buffer holding the last query rows
+        self._host: Optional[np.ndarray] = None
+        self.hits = 0                       # calls whose train side was served from the device
+        self.calls = 0
+
+    def _buffer(self, which: int, rows: int) -> DeviceBuffer:
+        need = max(rows, 1) * DESC_BYTES
+        b = self._bufs[which]
+        if b is None or b.nbytes < need:
+            if b is not None:
+                b.free()
+            b = self._bufs[which] = self.ctx.malloc(max(need, 256 * DESC_BYTES) * 2)
+        return b
+
+    def lookup(self, t: np.ndarray) -> Optional[DeviceBuffer]:
+        """The device copy of ``t`` if it is the matrix remembered from the last call."""
+        h = self._host
+        if h is None or h.shape != t.shape or not np.array_equal(h, t):
+            return None
+        return self._bufs[self._cur]
+
+    def next_buffer(self, rows: int) -> DeviceBuffer:
+        return self._buffer(self._cur ^ 1, rows)
+
+    def remember(self, q: np.ndarray) -> None:
+        self._cur ^= 1
+        self._host = q.copy()
+
+    def forget(self) -> None:
+        self._host = None
+
+    def free(self) -> None:
+        for b in self._bufs:
+            if b is not None:
+                b.free()
+        self._bufs, self._host = [None, None], None
+
+
+def match_arrays(source, query, dist_threshold: Optional[float] = None, ctx: Optional[Context] = None,
+                 cache: Optional[FrameCache] = None):
     """``BruteForceFeatureMatcher.match`` as arrays (``feature_matchers.py:36-44``).
 
     Note the reference's argument order: first the train ("source", last frame)
     descriptors, then the query (current frame).  Returns (queryIdx, trainIdx,
     distance float32), one entry per match, ascending queryIdx; the
-    ``dist_threshold`` filter keeps ``distance < max(2*min_dist, dist_threshold)``."""
+    ``dist_threshold`` filter keeps ``distance < max(2*min_dist, dist_threshold)``.
+    With a ``cache`` (see ``FrameCache``) a source matrix equal to the previous call's
+    query matrix is not uploaded again."""
     q, t = as_descriptors(query), as_descriptors(source)
-    ctx = ctx or default_context()
+    ctx = ctx or (cache.ctx if cache is not None else default_context())
     mode = MODE_MIN_DIST if dist_threshold else MODE_ALL   # `if dist_threshold and ...` (feature_matchers.py:41)
-    return _match_host(ctx, q, t, None, t.shape[0], None, mode, float(dist_threshold or 0.0))
+    param = float(dist_threshold or 0.0)
+    n, m = q.shape[0], t.shape[0]
+    if cache is None or n > FrameCache.MAX_ROWS or m > FrameCache.MAX_ROWS:
+        return _match_host(ctx, q, t, None, m, None, mode, param)
+    cache.calls += 1
+    d_train = cache.lookup(t) if m else None
+    keep = cache.next_buffer(n) if n else None
+    try:
+        out = _match_host(ctx, q, None if d_train is not None else t, d_train, m, keep, mode, param)
+    except Exception:
+        cache.forget()
+        raise
+    if d_train is not None:
+        cache.hits += 1
+    if n:
+        cache.remember(q)
+    else:
+        cache.forget()
+    return out
 
 
 def ratio_test_arrays(query, train, ratio: float = 0.75, ctx: Optional[Context] = None):
@@ -150,8 +210,10 @@ def ratio_test_arrays(query, train, ratio: float = 0.75, ctx: Optional[Context] 
 
 
 def cross_check_arrays(query, train, ctx: Optional[Context] = None):
-    """``cv2.BFMatcher(NORM_HAMMING, crossCheck=True).match(query, train)`` as arrays: one library call
-    (reverse search + selection on the device, ``slam_bf_match_host`` mode 3)."""
+    """``cv2.BFMatcher(NORM_HAMMING, crossCheck=True).match(query, train)`` as arrays: the pairs (q, t) where t is
+    q's nearest train row and q is t's nearest query row (ties to the lowest index on both sides, as OpenCV 4.x's
+    ``batchDistance`` crosscheck branch decides them).  One library call: forward search, reverse search and the
+    selection all stay on the device (``slam_bf_match_host`` mode 3)."""
     q, t = as_descriptors(query), as_descriptors(train)
     ctx = ctx or default_context()
     return _match_host(ctx, q, t, None, t.shape[0], None, MODE_CROSS, 0.0)

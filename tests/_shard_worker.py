@@ -1,4 +1,4 @@
-"""Worker for test_comm_gpu.py: one rank of a sharded search (run under torch.distributed.run; every rank on GPU 0).
+"""Worker for test_comm_gpu.py: one rank of a sharded search (started by slamhip.launch.spawn_ranks; every rank on GPU 0).
 
 Not collected by pytest (leading underscore).  argv[1] = "query" | "train": which partitioning to run.  The ranks
 gather through the peer-copy tier (RCCL refuses ranks that share a GPU) and compare with the oracle."""
@@ -13,32 +13,27 @@ for p in (os.path.join(ROOT, "slam-experiments_amd"), ROOT):
 
 
 def main() -> int:
-    import torch.distributed as dist
-
     import slamhip
     from oracle import oracle
     from slamhip.dist import ShardedMatcher, TrainShardedMatcher
+    from slamhip.launch import Rendezvous, from_env
 
     mode = sys.argv[1]
-    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rank, _, world, name = from_env()
+    rz = Rendezvous(rank, world, name)
     ctx = slamhip.Context(0)
-
-    def allgather_obj(x):
-        out = [None] * world
-        dist.all_gather_object(out, x)
-        return out
+    allgather_obj = rz.allgather
 
     def barrier():
         ctx.sync()
-        dist.barrier()
+        rz.barrier()
 
     rng = np.random.default_rng(99)
-    n, m = (3001, 7000) if mode == "query" else (500, 9001)     # ragged on purpose: tail shards are shorter
+    n, m = {"query": (3001, 7000), "train": (500, 9001), "train1": (1, 700)}[mode]   # ragged on purpose; train1: 8-byte slots
     query = rng.integers(0, 256, (n, 32), dtype=np.uint8)
     train = rng.integers(0, 256, (m, 32), dtype=np.uint8)
     train[m // 2:m // 2 + 50] = train[:50]                      # duplicates across the shard boundary: tie rule
-    query[:50] = train[:50]
+    query[:min(n, 50)] = train[:min(n, 50)]
     if mode == "query":
         sm = ShardedMatcher(ctx, rank, world, query, train, collective=None)
     else:
@@ -52,11 +47,15 @@ def main() -> int:
     idx, d = sm.result()
     ei, ed = oracle.bf_knn_c(query, train, 2, threads=4)
     good = bool(ok and sm.collective == "p2p" and np.array_equal(idx, ei) and np.array_equal(d, ed))
-    barrier()
-    sm.free()
+    try:
+        sm.free()                                                # peers are mapped: freeing without the barrier must refuse
+        good = False
+    except RuntimeError:
+        pass
+    sm.free(barrier)                                             # unmap -> barrier -> free
     ctx.close()
     verdicts = allgather_obj(good)
-    dist.destroy_process_group()
+    rz.close()
     if rank == 0:
         print("SHARD_WORKER_OK" if all(verdicts) else f"SHARD_WORKER_FAILED {verdicts}")
     return 0 if all(verdicts) else 1

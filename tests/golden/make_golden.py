@@ -79,19 +79,34 @@ dump("kat_filter.json", {
     ],
 })
 
-# 5. crossCheck (OpenCV batch_distance.cpp crosscheck branch, K = 1).
-#    queries q0 = prefix(10), q1 = prefix(20); train t0 = prefix(12), t1 = prefix(11), t2 = prefix(30).
-#    reverse 1-NN: t0 -> q0 (2; q1 is 8), t1 -> q0 (1), t2 -> q1 (10; q0 is 20).
-#    scanning t ascending with strict "<": q0 gets t0 (2) then t1 (1 < 2) -> (t1, 1); q1 gets t2 (10).
-#    Note q1's own nearest train row is t0 (8), yet it is matched to t2: OpenCV's one-pass rule, restated as is.
-#    Second case: query prefix(100) is nobody's nearest -> no match for it.
+# 5. crossCheck (OpenCV 4.x batch_distance.cpp crosscheck branch, K = 1; documented contract of
+#    BFMatcher(crossCheck=True): "(i, j) such that for i-th query descriptor the j-th descriptor in the matcher's
+#    collection is the nearest and vice versa").  The branch computes the reverse table tidx (train row -> nearest
+#    query), the forward table sidx (query -> nearest train row), scatters ascending train rows with strict "<",
+#    and finally clears every query i with tidx[sidx[i]] != i.
+#    Case 1: queries q0 = prefix(10), q1 = prefix(20); train t0 = prefix(12), t1 = prefix(11), t2 = prefix(30).
+#      d(q0, .) = (2, 1, 20) -> sidx[q0] = t1;   d(q1, .) = (8, 9, 10) -> sidx[q1] = t0.
+#      d(t0, .) = (2, 8) -> tidx[t0] = q0; d(t1, .) = (1, 9) -> tidx[t1] = q0; d(t2, .) = (20, 10) -> tidx[t2] = q1.
+#      scatter: q0 <- t0 (2), then t1 (1 < 2) -> (t1, 1); q1 <- t2 (10).
+#      forward check: tidx[sidx[q0] = t1] = q0 -> kept (t1, 1); tidx[sidx[q1] = t0] = q0 != q1 -> cleared.
+#      Result [1, -1].  (Round 1 had [1, 2] here: the scatter alone, without the forward pass - a non-mutual pair.)
+#    Case 2: query prefix(100) inserted as q1: d(q1, .) = (88, 89, 70) -> sidx = t2, tidx[t2] = q2 (10 < 70) -> cleared;
+#      q2 = prefix(20) as q1 of case 1 -> cleared.  Result [1, -1, -1].
+#    Case 3, ties on both sides: queries q0 = q1 = prefix(8), q2 = prefix(40); train t0 = t1 = prefix(8), t2 = prefix(41),
+#      t3 = prefix(39).  sidx = (t0, t0, t2) [q2: d = (32, 32, 1, 1) -> lowest index t2]; tidx = (q0, q0, q2, q2).
+#      q0: tidx[t0] = q0 kept (t0, 0).  q1: tidx[t0] = q0 != q1 cleared (its duplicate took the row).
+#      q2: tidx[t2] = q2 kept (t2, 1) - not t3, although t3 is equally near and also points at q2.
+#      Result idx [0, -1, 2], dist [0, -, 1].
 dump("kat_cross_check.json", {
-    "doc": "cv2.BFMatcher(NORM_HAMMING, crossCheck=True).match(query, train)",
+    "doc": "cv2.BFMatcher(NORM_HAMMING, crossCheck=True).match(query, train): mutual nearest neighbours only",
     "query": [prefix_ones(10), prefix_ones(20)],
     "train": [prefix_ones(12), prefix_ones(11), prefix_ones(30)],
-    "out_idx": [1, 2], "out_dist": [1, 10],
+    "out_idx": [1, -1], "out_dist": [1, INT_MAX],
     "query2": [prefix_ones(10), prefix_ones(100), prefix_ones(20)],
-    "out_idx2": [1, -1, 2], "out_dist2": [1, INT_MAX, 10],
+    "out_idx2": [1, -1, -1], "out_dist2": [1, INT_MAX, INT_MAX],
+    "query3": [prefix_ones(8), prefix_ones(8), prefix_ones(40)],
+    "train3": [prefix_ones(8), prefix_ones(8), prefix_ones(41), prefix_ones(39)],
+    "out_idx3": [0, -1, 2], "out_dist3": [0, INT_MAX, 1],
 })
 
 # 6. Lowe ratio (d0 < ratio * d1, strict): train popcounts 0 and 8; query prefix(2): d = (2, 6): 2 < 0.75*6 = 4.5 keep;

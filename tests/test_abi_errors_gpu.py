@@ -25,7 +25,18 @@ def test_status_codes_and_messages(gpu_ctx):
     assert lib.slam_bf_knn2_u256(ctx.handle, q.ptr, 8, q.ptr, 8, 0, None, out.ptr) == -1
     assert lib.slam_bf_knn2_u256(ctx.handle, q.ptr, 8, q.ptr, 8, 2**31 - 4, out.ptr, out.ptr) == -1
     assert lib.slam_bf_match_filter(ctx.handle, out.ptr, out.ptr, 8, 7, 0.0, out.ptr, None, None) == -1
-    assert lib.slam_bf_set_tuning(3, 0) == -1
+    knobs = lambda *v: (ctypes.c_int32 * len(v))(*v)
+    assert lib.slam_bf_set_tuning(ctx.handle, knobs(3), 1) == -1                       # R not in {1, 2, 4, 8}
+    assert lib.slam_bf_set_tuning(None, knobs(1), 1) == -1 and lib.slam_bf_set_tuning(ctx.handle, knobs(1, 0, -2), 3) == -1
+    assert lib.slam_bf_set_tuning(ctx.handle, knobs(1, 0, 64, 48), 4) == -1            # leader chunk not a multiple of 32
+    assert lib.slam_bf_set_tuning(ctx.handle, None, 3) == -1 and lib.slam_bf_set_tuning(ctx.handle, knobs(*[0] * 7), 7) == -1
+    assert lib.slam_bf_set_tuning(ctx.handle, None, 0) == 0                            # reset to the shipped plan
+    plan = (ctypes.c_int32 * 8)()
+    assert lib.slam_bf_plan_info(ctx.handle, 65536, 65536, plan) == 0
+    assert plan[0] == 1 and plan[1] == 256 and plan[4] % 32 == 0 and plan[3] >= 8
+    assert lib.slam_bf_plan_info(ctx.handle, 200, 200, plan) == 0 and plan[4] == 0     # frame-sized: no leaders
+    assert lib.slam_bf_plan_info(ctx.handle, 0, 5, plan) == -1
+    assert lib.slam_bf_reset_state(ctx.handle) == 0 and lib.slam_bf_reset_state(None) == -1
     # freeing a pointer the context does not own
     assert lib.slam_free(ctx.handle, 0x1000) == -1 and b"not owned" in lib.slam_last_error()
     with pytest.raises(SlamHipError):
@@ -148,7 +159,7 @@ def test_host_calls_from_two_threads_share_a_context(gpu_ctx):
 
 @pytest.mark.parametrize("n,m", [(37, 53), (300, 120), (5000, 4500), (1, 9), (64, 1)])
 def test_cross_check_in_one_call(gpu_ctx, n, m):
-    """slam_bf_match_host mode 3 (crossCheck) against the oracle's one-pass OpenCV rule, host and device train."""
+    """slam_bf_match_host mode 3 (crossCheck) against the oracle (OpenCV 4.x crosscheck branch: mutual nearest neighbours), host and device train."""
     from oracle import oracle
 
     lib, ctx = gpu_ctx.lib, gpu_ctx

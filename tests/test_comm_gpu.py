@@ -47,44 +47,72 @@ def test_single_rank_communicator_allgather_and_broadcast(gpu_ctx):
         ctx.close()
 
 
+def _bench_line(out):
+    assert out.returncode == 0, (out.stdout[-500:], out.stderr[-3000:])
+    return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+
+
 def test_bench_under_the_driver_launcher_one_rank(built):
     """`python -m torch.distributed.run --nproc-per-node 1 bench.py --gpus 1` (the driver's launch line shape)."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
            "127.0.0.1", "--master-port", "29631", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3",
-           "--warmup", "1", "--no-cpu-baseline", "--no-reproj"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
-    assert out.returncode == 0, out.stderr[-2000:]
-    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
-    rec = json.loads(line)
+           "--warmup", "1", "--no-cpu-baseline", "--no-reproj", "--no-pipelined"]
+    rec = _bench_line(subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT))
     assert rec["n_gpus"] == 1 and rec["parity_spot_check"] is True and rec["value"] > 1e11
     assert rec["roofline"]["kernel_ms"] > 0 and rec["unit"] == "pairs/s"
 
 
-@pytest.mark.parametrize("force,expect", [("", ("rccl", "xgmi-p2p-copies")), ("gloo", ("gloo-host-fallback",))])
-def test_two_ranks_on_one_gpu_take_the_loud_fallbacks(built, force, expect):
-    """Two ranks sharing GPU 0: RCCL refuses duplicate devices, so this exercises the rendezvous, the failure
-    handling and the next tiers of bench.py end to end - the peer-copy all-gather through HIP IPC mappings (a real
-    device-to-device gather between two processes), and with SLAM_BENCH_COLLECTIVE=gloo the host gather below it.
-    Either way the sharded result must equal the oracle spot check."""
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", SLAM_BENCH_SINGLE_DEVICE="1", SLAM_BENCH_COLLECTIVE=force)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", "29633" if force else "29635", os.path.join(ROOT, "bench.py"), "--gpus", "2",
-           "--steps", "3", "--warmup", "1"]
+@pytest.mark.parametrize("force,expect", [("", ("rccl", "xgmi-p2p-copies")), ("host", ("host-fallback",))])
+def test_self_contained_launch_two_ranks_on_one_gpu(built, force, expect):
+    """`python bench.py --gpus 2`, nothing else: bench.py starts its own rank processes (slamhip.launch, no torch).
+    Two ranks sharing GPU 0: RCCL refuses duplicate devices, so this exercises the rendezvous, the failure handling
+    and the next tiers end to end - the peer-copy all-gather through HIP IPC mappings (a real device-to-device gather
+    between two processes), and with SLAM_BENCH_COLLECTIVE=host the host gather below it.  Either way the sharded
+    result must equal the oracle spot check."""
+    env = dict(os.environ, SLAM_BENCH_SINGLE_DEVICE="1", SLAM_BENCH_COLLECTIVE=force)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SLAM_RDZV"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
-    assert out.returncode == 0, out.stderr[-3000:]
-    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    rec = _bench_line(out)
     assert rec["n_gpus"] == 2 and rec["parity_spot_check"] is True
     assert rec["config"]["collective"] in expect, (rec["config"]["collective"], out.stderr[-2000:])
-    assert rec["cpu_baseline"] is None
+    assert rec["cpu_baseline"] is None and "N=1" in rec["cpu_baseline_note"]
 
 
-@pytest.mark.parametrize("mode,port", [("query", "29641"), ("train", "29643")])
-def test_sharded_matchers_between_processes(built, mode, port):
-    """Three ranks on GPU 0 under torch.distributed.run: the query-sharded and the train-sharded matcher of
-    slamhip.dist gather through IPC peer copies (ragged shards, several passes) and must equal the oracle."""
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr",
-           "127.0.0.1", "--master-port", port, os.path.join(ROOT, "tests", "_shard_worker.py"), mode]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+def test_driver_launch_line_two_ranks_needs_no_torch_in_the_ranks(built):
+    """The driver's N > 1 line (`python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2`): the ranks read
+    RANK / WORLD_SIZE / MASTER_PORT from the environment and rendezvous through slamhip.launch; torch stays the
+    launcher's business (a sitecustomize hook makes `import torch` inside a rank fail the run)."""
+    hook = os.path.join(ROOT, "gpurun_out", "_no_torch_hook")
+    os.makedirs(hook, exist_ok=True)
+    with open(os.path.join(hook, "sitecustomize.py"), "w") as f:
+        f.write("import os, sys\n"
+                "if os.environ.get('RANK') is not None and sys.argv and sys.argv[0].endswith('bench.py'):\n"
+                "    import importlib.abc\n"
+                "    class _Deny(importlib.abc.MetaPathFinder):\n"
+                "        def find_spec(self, name, path, target=None):\n"
+                "            if name == 'torch' or name.startswith('torch.'):\n"
+                "                raise ImportError('torch imported inside a bench.py rank')\n"
+                "    sys.meta_path.insert(0, _Deny())\n")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", SLAM_BENCH_SINGLE_DEVICE="1",
+               PYTHONPATH=hook + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29637", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"]
+    rec = _bench_line(subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT))
+    assert rec["n_gpus"] == 2 and rec["parity_spot_check"] is True
+
+
+@pytest.mark.parametrize("mode", ["query", "train", "train1"])
+def test_sharded_matchers_between_processes(built, mode):
+    """Three ranks on GPU 0 (slamhip.launch.spawn_ranks): the query-sharded and the train-sharded matcher of slamhip.dist
+    gather through IPC peer copies (ragged shards, several passes, a one-query train-sharded case with 8-byte slots)
+    and must equal the oracle; freeing peer-mapped buffers without the barrier is refused."""
+    from slamhip.launch import spawn_ranks  # noqa: F401  (the child interpreter below does the spawning)
+
+    code = ("import sys; sys.path.insert(0, %r); from slamhip.launch import spawn_ranks; "
+            "sys.exit(spawn_ranks(%r, [%r], 3, timeout=500))") % (
+                os.path.join(ROOT, "slam-experiments_amd"), os.path.join(ROOT, "tests", "_shard_worker.py"), mode)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0 and "SHARD_WORKER_OK" in out.stdout, (out.stdout[-500:], out.stderr[-2500:])

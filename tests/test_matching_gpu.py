@@ -34,10 +34,10 @@ def test_every_kernel_variant(gpu_ctx, R, bpc):
     t[100:140] = t[7]          # 41-way tie on one row
     q[3] = t[7]
     try:
-        assert lib.slam_bf_set_tuning(R, bpc) == 0
+        gpu_ctx.set_tuning(R=R, blocks_per_cu=bpc)
         idx, dist = slamhip.knn_match_arrays(q, t, 2)
     finally:
-        lib.slam_bf_set_tuning(0, 0)
+        gpu_ctx.set_tuning()
     ridx, rdist = oracle.bf_knn_c(q, t, 2, threads=8)
     assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist)
     assert idx[3].tolist() == [7, 100] and dist[3].tolist() == [0, 0]
@@ -260,13 +260,13 @@ def test_repeated_calls_keep_the_merge_state_clean(gpu_ctx):
     try:
         for rep in range(3):
             for R, bpc in ((1, 0), (2, 8), (1, 64), (4, 2), (8, 1)):
-                lib.slam_bf_set_tuning(R, bpc)
+                gpu_ctx.set_tuning(R=R, blocks_per_cu=bpc)
                 idx, dist = slamhip.knn_match_arrays(q, t, 2)
                 assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist), (rep, R, bpc)
                 small = slamhip.knn_match_arrays(q[:100], t[:77], 2)
                 assert np.array_equal(small[0], oracle.bf_knn_c(q[:100], t[:77], 2)[0])
     finally:
-        lib.slam_bf_set_tuning(0, 0)
+        gpu_ctx.set_tuning()
 
 
 def test_train_set_larger_than_one_key_range(gpu_ctx):

@@ -302,3 +302,87 @@ def test_backend_corrects_a_frame_pose_in_place(gpu_ctx):
     assert not any(ft.is_outlier for ft in frame.features)
     empty = Frame(Pose(np.eye(4)))
     assert Backend().correct_frame_pose(empty, FX, FY, CX, CY) == 0
+
+
+# ---- f3 / f4 against the CPU oracle (oracle/oracle.py: pose_lm_np, ba_schur_np — nothing of the HIP library) ----------
+@pytest.mark.parametrize("O,seed", [(200, 228), (64, 1), (257, 2), (3000, 3), (12, 4)])
+def test_device_lm_matches_oracle(gpu_ctx, O, seed):
+    """slam_pose_optimize_f64 (one launch: the whole four-round LM of frontend.py:298-393) against the oracle's
+    independent f64 LM (C normal equations + numpy solve + scipy matrix exponential): same pose to 1e-8, the same
+    inlier set, chi2 to 1e-6 relative; the host-driven loop over slam_pose_normal_eq_f64 is held to the same oracle."""
+    from backend import Backend
+    from oracle import oracle
+
+    rng = np.random.default_rng(seed)
+    T, X = _scene(rng, 1, O)
+    meas = _project(T[0], X) + rng.normal(0, 0.4, (O, 2))
+    bad = np.arange(0, O, 7)
+    meas[bad] += rng.uniform(40, 120, (len(bad), 2)) * rng.choice([-1, 1], (len(bad), 2))
+    meas = meas.astype(np.int32).astype(np.float64)                  # int-truncated pixels (primitives.py:110-112)
+    T_init = oracle.se3_exp_np(rng.normal(0, 0.02, 6)) @ T[0]
+    Tr, inl, chi2, acc = oracle.pose_lm_np(T_init, X, meas, FX, FY, CX, CY)
+    for on_device in (True, False):
+        got = Backend().optimize_pose(T_init, X, meas, FX, FY, CX, CY, on_device=on_device)
+        assert np.allclose(got.pose, Tr, rtol=0, atol=1e-8), (on_device, np.abs(got.pose - Tr).max())
+        assert np.array_equal(got.inliers, inl) and got.n_inliers == int(inl.sum())
+        assert np.allclose(got.chi2, chi2, rtol=1e-6, atol=1e-6)
+        assert abs(got.iterations - acc) <= 8      # at convergence the cost differences are rounding noise: last steps may flip
+    is_bad = np.zeros(O, bool)
+    is_bad[bad] = True
+    assert not inl[is_bad].any() and inl[~is_bad].mean() > 0.95
+
+
+def test_device_lm_schedule_variants_match_oracle(gpu_ctx):
+    """Other round / iteration counts, no robust kernel, a tighter gate: the schedule itself is what is compared."""
+    import ctypes
+
+    from oracle import oracle
+
+    rng = np.random.default_rng(99)
+    O = 150
+    T, X = _scene(rng, 1, O)
+    meas = _project(T[0], X) + rng.normal(0, 0.5, (O, 2))
+    meas[::5] += 30.0
+    T_init = oracle.se3_exp_np(rng.normal(0, 0.03, 6)) @ T[0]
+    lib, ctx = gpu_ctx.lib, gpu_ctx
+    for rounds, iters, thr, delta in ((1, 10, 35.89, 1.0), (2, 3, 9.0, 0.0), (4, 10, 5.991, 2.5), (3, 1, 35.89, 1.0)):
+        Tr, inl, chi2, acc = oracle.pose_lm_np(T_init, X, meas, FX, FY, CX, CY, rounds, iters, thr, delta)
+        out12, hin, hchi, st = np.empty(12), np.zeros(O, np.uint8), np.zeros(O), np.zeros(2, np.int32)
+        pin = np.ascontiguousarray(T_init[:3, :4].reshape(12))
+        assert lib.slam_pose_optimize_host_f64(ctx.handle, pin.ctypes.data, X.ctypes.data, meas.ctypes.data, O, FX, FY, CX, CY,
+                                               rounds, iters, thr, delta, out12.ctypes.data, hin.ctypes.data,
+                                               hchi.ctypes.data, st.ctypes.data) == 0
+        assert np.allclose(out12.reshape(3, 4), Tr[:3, :4], rtol=0, atol=1e-8), (rounds, iters, thr, delta)
+        assert np.array_equal(hin.astype(bool), inl) and st[0] == inl.sum()
+        assert np.allclose(hchi, chi2, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("K,L,delta", [(7, 300, 0.0), (3, 40, 1.5), (16, 600, 2.0), (1, 5, 0.0)])
+def test_reduce_matches_oracle(gpu_ctx, K, L, delta):
+    """slam_ba_reduce_f64 / slam_ba_backsub_f64 against the oracle's Schur reduction, which is computed from the C
+    oracle's residuals and Jacobians (not from anything a HIP kernel produced): S, rhs, bp, bl, cost, dl <= 1e-9 relative."""
+    from oracle import oracle
+    from slamhip.ba import SchurProblem
+
+    rng = np.random.default_rng(2000 * K + L)
+    T, X, op, ol, meas = _window(rng, K, L, noise=1.0)
+    if L > 5:                                           # one point nobody observes
+        sel = ol != L - 1
+        op, ol, meas = op[sel], ol[sel], meas[sel]
+    lam = 2.3
+    P12 = T[:, :3, :4].reshape(K, 12)
+    red = oracle.ba_schur_np(P12, X, op, ol, meas, FX, FY, CX, CY, delta, lam)
+    tol = lambda ref: 1e-9 * max(np.abs(ref).max(), 1e-300)
+    sp = SchurProblem(gpu_ctx, K, L, op, ol, meas, (FX, FY, CX, CY))
+    try:
+        S_d, rhs_d, bp_d, cost_d = sp.reduce(P12, X, delta, lam)
+        assert np.abs(S_d - red["S"]).max() <= tol(red["S"])
+        assert np.abs(rhs_d - red["rhs"]).max() <= tol(red["rhs"]) and np.abs(bp_d - red["bp"]).max() <= tol(red["bp"])
+        assert abs(cost_d - red["cost"]) <= 1e-9 * max(red["cost"], 1.0)
+        dp = rng.normal(0, 1e-3, (K, 6))
+        dl_d, bl_d = sp.back_substitute(dp)
+        dl = oracle.ba_backsub_np(red, op, ol, dp)
+        assert np.abs(bl_d - red["bl"]).max() <= tol(red["bl"]) and np.abs(dl_d - dl).max() <= tol(dl)
+        assert (dl_d[~red["seen"]] == 0).all()
+    finally:
+        sp.free()

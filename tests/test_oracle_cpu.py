@@ -55,6 +55,12 @@ def test_cross_check(cc):
     assert oi.tolist() == g["out_idx"] and od.tolist() == g["out_dist"]
     oi, od = cc(d(g["query2"]), d(g["train"]))
     assert oi.tolist() == g["out_idx2"] and od.tolist() == g["out_dist2"]
+    oi, od = cc(d(g["query3"]), d(g["train3"]))
+    assert oi.tolist() == g["out_idx3"] and od.tolist() == g["out_dist3"]
+    # no train rows / no query rows: nothing to pair
+    oi, od = cc(d(g["query"]), np.zeros((0, 32), np.uint8))
+    assert oi.tolist() == [-1, -1] and od.tolist() == [INT_MAX, INT_MAX]
+    assert cc(np.zeros((0, 32), np.uint8), d(g["train"]))[0].shape == (0,)
 
 
 def test_ratio():

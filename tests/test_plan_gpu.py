@@ -1,0 +1,95 @@
+"""GPU: the launch plan of the top-2 search (leader chunks at raised priority that publish exact bounds, optional
+wait for them, shrinking chunks at the end of the grid) must not change a single bit of the result."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _search(ctx, dq, n, dt, m, tab):
+    import slamhip
+
+    slamhip.knn2_device(ctx, dq.buf, n, dt.buf, m, tab.idx, tab.dist)
+    return tab.download()
+
+
+@pytest.mark.parametrize("n,m", [(300, 1500), (1000, 5000), (257, 769), (64, 16384), (5000, 20000)])
+def test_every_plan_shape_is_bit_identical(gpu_ctx, n, m):
+    import slamhip
+    from oracle import oracle
+
+    ctx = gpu_ctx
+    rng = np.random.default_rng(n * 7 + m)
+    q = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    t = rng.integers(0, 256, (m, 32), dtype=np.uint8)
+    # ties across the leader / rest boundary: the same row before and after it, exact copies of queries on both sides
+    t[m - 3] = t[5]
+    t[m // 2] = t[5]
+    q[0] = t[5]
+    q[1] = t[m - 1]
+    ridx, rdist = oracle.bf_knn_c(q, t, 2, threads=8)
+    assert ridx[0].tolist() == [5, m // 2] and rdist[0].tolist() == [0, 0]
+    dq, dt = slamhip.DeviceDescriptors(ctx, q), slamhip.DeviceDescriptors(ctx, t)
+    tab = slamhip.Top2Table(ctx, n)
+    try:
+        for R in (1, 2, 4, 8):
+            for lead_rows, lead_chunk in ((-1, 0), (256, 0), (512, 64), (1024, 32), (0, 0)):
+                for bpc, prio, tail in ((0, 0, 0), (8, 1, 5), (0, 1, 64), (32, 0, 3)):
+                    ctx.set_tuning(R=R, blocks_per_cu=bpc, lead_rows=lead_rows, lead_chunk=lead_chunk, lead_prio=prio, tail=tail)
+                    idx, dist = _search(ctx, dq, n, dt, m, tab)
+                    assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist), (R, lead_rows, lead_chunk, bpc, prio, tail)
+    finally:
+        ctx.set_tuning()
+        for o in (tab, dq, dt):
+            o.free()
+
+
+def test_plan_tables_and_degenerate_inputs(gpu_ctx):
+    """Shipped plans: leaders from 16384 train rows up, none for frame-sized inputs; forced plans cover the train set
+    exactly; all-equal rows (every distance ties) and train sets whose best rows all sit in / behind the leader rows."""
+    import slamhip
+    from oracle import oracle
+
+    ctx = gpu_ctx
+    for m, lead in ((200, 0), (16383, 0), (16384, 1024), (65536, 4096), (1 << 20, 4096)):
+        p = ctx.plan_info(8192, m)
+        assert p["lead_rows"] == lead and (p["lead_chunks"] > 0) == (lead > 0), (m, p)
+    try:
+        ctx.set_tuning(lead_rows=1000, lead_chunk=96, tail=9, blocks_per_cu=16)
+        p = ctx.plan_info(5000, 30000)
+        assert p["lead_rows"] == 992 and p["lead_chunks"] == 11 and p["tail_chunks"] == 9 and p["chunks"] > 20
+    finally:
+        ctx.set_tuning()
+    n, m = 700, 20000
+    rng = np.random.default_rng(3)
+    q = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    for case in ("zeros", "front", "back"):
+        if case == "zeros":
+            t = np.zeros((m, 32), np.uint8)
+        else:
+            t = rng.integers(0, 256, (m, 32), dtype=np.uint8)
+            rows = np.arange(n) if case == "front" else m - 1 - np.arange(n)
+            t[rows] = q                                         # every query has an exact copy in / behind the leader rows
+        for wait in (0, 1):
+            try:
+                ctx.set_tuning(lead_prio=wait - 1, tail=7 * wait)
+                idx, dist = slamhip.knn_match_arrays(q, t, 2, ctx=ctx)
+            finally:
+                ctx.set_tuning()
+            ridx, rdist = oracle.bf_knn_c(q, t, 2, threads=8)
+            assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist), (case, wait)
+
+
+def test_reset_state_between_searches(gpu_ctx):
+    """slam_bf_reset_state puts best/bound/arrivals/led back: searches before and after it agree with the oracle."""
+    import slamhip
+    from oracle import oracle
+
+    ctx, lib = gpu_ctx, gpu_ctx.lib
+    q = np.random.default_rng(1).integers(0, 256, (900, 32), dtype=np.uint8)
+    t = np.random.default_rng(2).integers(0, 256, (17000, 32), dtype=np.uint8)
+    ridx, rdist = oracle.bf_knn_c(q, t, 2, threads=8)
+    for _ in range(2):
+        idx, dist = slamhip.knn_match_arrays(q, t, 2, ctx=ctx)
+        assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist)
+        assert lib.slam_bf_reset_state(ctx.handle) == 0

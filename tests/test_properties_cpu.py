@@ -57,3 +57,35 @@ def test_match_filter_is_a_subset_with_strict_limit(src, qry, thr):
         assert (d1.astype(np.float64) < lim).all() and len(d1) == int((d0.astype(np.float64) < lim).sum())
     else:
         assert np.array_equal(q0, q1)
+
+
+def low_entropy_descs(n_max):
+    """Rows drawn from a handful of byte patterns: equal distances (ties) on both sides are the rule."""
+    return st.integers(0, n_max).flatmap(
+        lambda n: st.lists(st.lists(st.sampled_from([0x00, 0xFF, 0x0F]), min_size=2, max_size=2), min_size=n, max_size=n)
+        .map(lambda rows: np.array([r * 16 for r in rows], np.uint8).reshape(n, 32)))
+
+
+def mutual_pairs(q, t):
+    """The contract of BFMatcher(crossCheck=True), spelled out with explicit loops: (i, j) iff j is the first nearest
+    train row of i and i is the first nearest query row of j."""
+    d = oracle.hamming_matrix_np(q, t)
+    pairs = {}
+    for i in range(len(q)):
+        j = min(range(len(t)), key=lambda c: (d[i, c], c))
+        back = min(range(len(q)), key=lambda r: (d[r, j], r))
+        if back == i:
+            pairs[i] = (j, int(d[i, j]))
+    return pairs
+
+
+@settings(max_examples=80, deadline=None, derandomize=True)
+@given(st.one_of(descs(25), low_entropy_descs(25)), st.one_of(descs(30), low_entropy_descs(30)))
+def test_cross_check_returns_exactly_the_mutual_nearest_pairs(q, t):
+    for cc in (oracle.bf_cross_check_c, oracle.bf_cross_check_np):
+        oi, od = cc(q, t)
+        got = {i: (int(oi[i]), int(od[i])) for i in range(len(q)) if oi[i] >= 0}
+        exp = mutual_pairs(q, t) if len(q) and len(t) else {}
+        assert got == exp
+        assert (od[oi < 0] == 2**31 - 1).all()
+        assert len(set(v[0] for v in got.values())) == len(got)      # a train row is paired at most once

@@ -1,0 +1,65 @@
+"""Per-block timeline of one top-2 launch (development aid; needs the experiment build tools/exp/libslamhip_trace.so,
+which stamps wall_clock64() at block start / after the prologue / after the scan / at the end).
+
+    python tools/trace_probe.py NxM [seed_rows] [blocks_per_cu]
+"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "slam-experiments_amd"))
+import slamhip  # noqa: E402
+from slamhip import _lib  # noqa: E402
+
+_lib.LIB_PATH = os.path.join(ROOT, "tools", "exp", "libslamhip_trace.so")
+n, m = (int(v) for v in sys.argv[1].split("x"))
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else -1
+bpc = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+prio = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+tail = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+ctx = slamhip.Context(0)
+lib, h = ctx.lib, ctx.handle
+lib.slam_exp_set_trace.argtypes = [ctypes.c_void_p]
+ctx.set_tuning(blocks_per_cu=bpc, lead_rows=seed, lead_prio=prio, tail=tail)
+plan = (ctypes.c_int32 * 8)()
+lib.slam_bf_plan_info(h, n, m, plan)
+blocks = plan[1] * plan[3]
+q = slamhip.DeviceDescriptors(ctx, np.random.default_rng(228).integers(0, 256, (n, 32), dtype=np.uint8))
+t = slamhip.DeviceDescriptors(ctx, np.random.default_rng(229).integers(0, 256, (m, 32), dtype=np.uint8))
+tab = slamhip.Top2Table(ctx, n)
+trace = ctx.malloc(blocks * 32)
+f = lambda: lib.slam_bf_knn2_u256(h, q.buf.ptr, n, t.buf.ptr, m, 0, tab.idx.ptr, tab.dist.ptr)
+for _ in range(30):
+    f()
+ctx.sync()
+assert lib.slam_exp_set_trace(trace.ptr) == 0
+ctx.timer_start()
+f()
+ms = ctx.timer_stop()
+tr = trace.download(np.uint64, (blocks, 4)).astype(np.int64)
+TICK = 0.01   # wall_clock64 runs at 100 MHz: 10 ns per tick, in us
+t0 = tr[:, 0].min()
+start, pro, scan, end = ((tr[:, i] - t0) * TICK for i in range(4))
+span = end.max()
+print(f"{n}x{m} plan chunk={plan[2]} S={plan[3]} qblocks={plan[1]} blocks={blocks} seed={plan[4]}: event time {ms * 1e3:.1f} us, "
+      f"first block start -> last block end {span:.1f} us")
+dur = end - start
+slots = plan[7] * 8
+print(f"block duration: mean {dur.mean():.1f} us, p5 {np.percentile(dur, 5):.1f}, p50 {np.percentile(dur, 50):.1f}, "
+      f"p95 {np.percentile(dur, 95):.1f}, max {dur.max():.1f}; prologue mean {np.mean(pro - start):.2f} us, "
+      f"scan mean {np.mean(scan - pro):.1f} us, epilogue mean {np.mean(end - scan):.2f} us (max {np.max(end - scan):.1f})")
+print(f"occupancy: sum(block time) / (span * {slots} slots) = {dur.sum() / (span * slots):.3f}")
+order = np.arange(blocks)
+for r in range(0, (blocks + slots - 1) // slots):
+    sel = (order >= r * slots) & (order < (r + 1) * slots)
+    print(f"  dispatch round {r}: start {start[sel].min():8.1f}..{start[sel].max():8.1f}  end {end[sel].min():8.1f}..{end[sel].max():8.1f}  "
+          f"mean duration {dur[sel].mean():7.1f}")
+bins = np.linspace(0, span, 41)
+act = [(np.minimum(end, b1) - np.maximum(start, b0)).clip(0).sum() / (b1 - b0) for b0, b1 in zip(bins[:-1], bins[1:])]
+print("active blocks per 1/40 of the span:", " ".join(f"{a:.0f}" for a in act))
+full = np.array(act) >= 0.97 * min(slots, blocks)
+print(f"time below 97 % of full residency: head {bins[1:][full][0] - bins[1] if full.any() else span:.1f} us, "
+      f"tail {span - bins[1:][full][-1] if full.any() else span:.1f} us")

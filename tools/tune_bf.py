@@ -20,7 +20,7 @@ tab = slamhip.Top2Table(ctx, n)
 ref = None
 for R in (1, 2, 4, 8, 1):
     for bpc in (0, 32):
-        lib.slam_bf_set_tuning(R, bpc)
+        ctx.set_tuning(R=R, blocks_per_cu=bpc)
         for _ in range(3):
             slamhip.knn2_device(ctx, dq.buf, n, dt.buf, m, tab.idx, tab.dist)
         ctx.sync()
@@ -39,4 +39,4 @@ for R in (1, 2, 4, 8, 1):
         pairs = n * m
         print(f"R={R} bpc={bpc:2d} total {ms:8.4f} ms kernel {kms / cnt:8.4f} ms  {pairs / (kms / cnt) / 1e6:8.1f} Gpairs/s "
               f"valu_frac(16.6 ops @2.4GHz)={pairs * 16.625 / (kms / cnt * 1e-3) / 7.864e13:.3f} same={ok}", flush=True)
-lib.slam_bf_set_tuning(0, 0)
+ctx.set_tuning()
