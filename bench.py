@@ -21,7 +21,7 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
                   bytes, as the contract asks, plus the VALU-integer figures that actually bound it;
   cpu_baseline  — the CPU oracle (oracle/bf_hamming_oracle.c, a port: cv2 is not installable
                   here) timed on the host cores over the same arrays (N = 1 only);
-  pipelined     — the same searches issued alternately on two contexts (N = 1 only; reported, not `value`);
+  pipelined     — with --pipelined: the same searches issued alternately on two contexts (N = 1 only; reported, not `value`);
   reproj        — the second hot path (residual/Jacobian build, 200 poses x 50k points dense)
                   with its own HBM roofline (only at the default N=1 run).
 """
@@ -244,7 +244,10 @@ def main() -> int:
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reproj", action="store_true")
-    ap.add_argument("--no-pipelined", action="store_true")
+    ap.add_argument("--pipelined", action="store_true",
+                    help="also time the searches alternating between two contexts (extra object `pipelined`; off by default "
+                         "so that a rocprofv3 summary of the default command only holds back-to-back launches)")
+    ap.add_argument("--no-pipelined", action="store_true", help=argparse.SUPPRESS)   # accepted for older command lines
     args = ap.parse_args()
 
     from slamhip.launch import Rendezvous, from_env, spawn_ranks
@@ -388,7 +391,7 @@ def main() -> int:
         elif not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(query, train)
     sm.free(barrier)                   # unmap peers -> barrier -> free the exported buffers (HIP IPC teardown order)
-    if rank == 0 and world == 1 and not args.no_pipelined:
+    if rank == 0 and world == 1 and args.pipelined:
         out["pipelined"] = pipelined_leg(query, train, max(args.steps, 20))
     if rank == 0 and world == 1 and not args.no_reproj:
         out["reproj"] = reproj_bench(ctx, max(3, min(args.steps, 20)), args.warmup, cpu=not args.no_cpu_baseline)

@@ -30,6 +30,10 @@
  *     and only read/written during the call.
  *   - a slam_ctx owns one HIP device + one HIP stream; calls on one ctx are
  *     stream-ordered, different ctxs are independent (one per thread / GPU).
+ *     The host-buffer entry points (*_host) may be called from several threads
+ *     on one ctx (they serialise on its staging block); the device-pointer
+ *     entry points share the ctx's workspace and merge state and expect ONE
+ *     calling thread per ctx at a time.
  *   - empty inputs are not errors: N == 0 is a no-op; M == 0 yields idx = -1,
  *     dist = INT32_MAX (OpenCV's "no neighbour").
  */
@@ -116,13 +120,12 @@ SLAM_API int slam_bf_knn2_u256_host(slam_ctx* ctx, const uint8_t* h_query, int64
  * entries and a NULL array mean 0 = the shipped choice):
  *   [0] R             queries per lane: 1, 2, 4 or 8 (shipped: 1)
  *   [1] blocks_per_cu grid size target (shipped: 32, or 64 for query sets with fewer query blocks than CUs)
- *   [2] lead_rows     train rows given to the leader chunks, which are dispatched first, run at raised wave priority
- *                     and publish exact per-query bounds (shipped: M/16 up to 4096 for M >= 16384, none below);
+ *   [2] lead_rows     train rows given to the leader chunks: short chunks at the head of the dispatch order that
+ *                     publish exact per-query bounds early (shipped: M/8 up to 8192 for M >= 16384, none below);
  *                     -1 = no leaders
  *   [3] lead_chunk    rows per leader chunk, a multiple of 32 (shipped: about one leader block per CU)
- *   [4] lead_prio     s_setprio level of the leader blocks: 1..3 (shipped: 3); -1 = leave them at priority 0
- *   [5] tail          number of linearly shrinking chunks at the end of the grid; -1 / 0 = none (shipped) */
-#define SLAM_BF_KNOBS 6
+ *   [4] tail          number of linearly shrinking chunks at the end of the grid (shipped: 16); -1 = none */
+#define SLAM_BF_KNOBS 5
 SLAM_API int slam_bf_set_tuning(slam_ctx* ctx, const int32_t* h_knobs, int count);
 /* The launch plan slam_bf_knn2_u256 would use for N x M on this context: h_plan int32 [8] =
  * {R, query blocks, uniform chunk rows, chunks, leader rows, leader chunks, shrinking tail chunks, CUs}. */
@@ -169,6 +172,13 @@ SLAM_API int slam_reproj_rj_f64(slam_ctx* ctx, const double* d_poses, int64_t K,
                        const double* d_meas, int64_t O,
                        double fx, double fy, double cx, double cy,
                        double* d_e, double* d_Jpose, double* d_Jpoint);
+
+/* d_obs_pose / d_obs_point entries must lie in [0, K) / [0, L).  slam_reproj_rj_f64 and the per-observation stage
+ * of slam_ba_reduce_f64 never dereference an index outside that range: the observation is computed from row 0
+ * with a NaN measurement (its e / J come out NaN) and a per-context counter is bumped.  slam_index_errors returns
+ * how many such observations were met since the last call and clears the counter (synchronises).  The derived
+ * tables of slam_ba_reduce_f64 (pt_ptr / pt_obs / ps_ptr / ps_obs / lookup) are the caller's to build correctly. */
+SLAM_API int slam_index_errors(slam_ctx* ctx, int64_t* count);
 
 /* Pose-only normal equations for one pose (frontend.py:298-365 inner build):
  * H = sum w J^T J (6x6, row-major), b = sum w J^T e (6), chi2[o] = e.e,

@@ -45,15 +45,24 @@ __global__ __launch_bounds__(BA_THREADS) void ba_obs_kernel(const double* __rest
                                                             const int* __restrict__ obs_pose,
                                                             const int* __restrict__ obs_point,
                                                             const double2* __restrict__ meas, int O, ba_cam cam,
-                                                            double delta, double* __restrict__ rec) {
+                                                            double delta, int K, int L,
+                                                            unsigned int* __restrict__ index_errors,
+                                                            double* __restrict__ rec) {
     const int o = blockIdx.x * BA_THREADS + threadIdx.x;
     if (o >= O) return;
-    const double* P = poses + (size_t)obs_pose[o] * 12;
-    const double* p = points + (size_t)obs_point[o] * 3;
+    int k = obs_pose[o], l = obs_point[o];
+    bool bad = false;
+    if ((unsigned)k >= (unsigned)K || (unsigned)l >= (unsigned)L) {   // reported (slam_index_errors), never dereferenced
+        atomicAdd(index_errors, 1u);
+        k = 0; l = 0; bad = true;
+    }
+    const double* P = poses + (size_t)k * 12;
+    const double* p = points + (size_t)l * 3;
     const double X = P[0] * p[0] + P[1] * p[1] + P[2] * p[2] + P[3];
     const double Y = P[4] * p[0] + P[5] * p[1] + P[6] * p[2] + P[7];
     const double Z = P[8] * p[0] + P[9] * p[1] + P[10] * p[2] + P[11];
-    const double2 m = meas[o];
+    double2 m = meas[o];
+    if (bad) m.x = m.y = __builtin_nan("");
     const double e0 = m.x - (cam.fx * X + cam.cx * Z) / Z;      // frontend.py:275-277
     const double e1 = m.y - (cam.fy * Y + cam.cy * Z) / Z;
     const double Zinv = 1.0 / (Z + 1e-18), Zinv2 = Zinv * Zinv;  // frontend.py:284-291
@@ -318,7 +327,8 @@ extern "C" int slam_ba_reduce_f64(slam_ctx* ctx, const double* d_poses, int64_t 
     const ba_cam cam = {fx, fy, cx, cy};
     if (O)
         ba_obs_kernel<<<(unsigned)((O + BA_THREADS - 1) / BA_THREADS), BA_THREADS, 0, ctx->stream>>>(
-            d_poses, d_points, d_obs_pose, d_obs_point, (const double2*)d_meas, (int)O, cam, huber_delta, d_rec);
+            d_poses, d_points, d_obs_pose, d_obs_point, (const double2*)d_meas, (int)O, cam, huber_delta, (int)K, (int)L,
+            slam_index_error_counter(ctx), d_rec);
     ba_point_kernel<<<(unsigned)((L + BA_THREADS - 1) / BA_THREADS), BA_THREADS, 0, ctx->stream>>>(
         d_pt_ptr, d_pt_obs, (int)L, lambda, d_rec, d_E, d_bl, d_hll_diag);
     ba_pose_kernel<<<(unsigned)K, BA_THREADS, 0, ctx->stream>>>(d_ps_ptr, d_ps_obs, d_obs_point, d_rec, d_bl, d_Hpp,

@@ -29,9 +29,10 @@
 //     2nd-best distance through a per-query bound in global memory (atomicMin +
 //     relaxed agent-scope load per tile, more often in a block's first tile), so
 //     a chunk does not start from an infinite threshold; a stale bound is only
-//     looser, never wrong.  The leader blocks (lowest grid.y, dispatched first)
-//     run at raised wave priority and publish the exact 2nd-best distance over
-//     their rows, so the rest of the grid gets a tight bound early.
+//     looser, never wrong.  The leader blocks (lowest grid.y, dispatched first,
+//     hence the oldest waves, which the age-ordered VALU arbiter serves first)
+//     are short and publish the exact 2nd-best distance over their rows, so the
+//     rest of the grid gets a tight bound early.
 //   * every block folds its top-2 into a per-query 64-bit slot with a CAS loop;
 //     the last block to arrive for a query block (agent-scope ticket) decodes
 //     the slots to (int32 idx, int32 dist) and restores the merge state, so a
@@ -124,6 +125,9 @@ __device__ __forceinline__ void filter_update(const u32 (&acc)[U][R], u32 first_
 // bound[q] only ever holds the 2nd-best distance over some subset of the train rows, i.e. an upper
 // bound of the final 2nd-best distance g: rows with d > g can be dropped, rows with d == g must stay
 // (they may win the tie on index), hence the "+ 1".  The load may be stale; that only loosens it.
+// (Measured and dropped: issuing the load at one share point and consuming it at the next, so that a wave never
+// sits on the round trip, makes every applied bound one segment staler - 64k x 64k 1528 -> 1551 us,
+// 8192 x 65536 212 -> 222 us, 2000 x 2000 21 -> 33 us.)
 template <int R>
 __device__ __forceinline__ void share_bound(u32* __restrict__ bound, int qbase, int N, const u32 (&b2)[R],
                                             u32 (&init)[R]) {
@@ -150,8 +154,7 @@ struct bf_state {
 
 // fold this block's (b1, b2) into best[q]: lock-free CAS loop, keys of different chunks are distinct.
 // Returns the 2nd key of the merged slot as this thread saw it (an upper bound of the final one).
-__device__ __forceinline__ u32 merge_into_slot(unsigned long long* slot, u32 b1, u32 b2) {
-    unsigned long long old = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__device__ __forceinline__ u32 merge_into_slot(unsigned long long* slot, unsigned long long old, u32 b1, u32 b2) {
     if (b1 == SLAM_KEY_NONE) return (u32)old;
     while (true) {
         const u32 o1 = (u32)(old >> 32), o2 = (u32)old;
@@ -167,14 +170,15 @@ __device__ __forceinline__ u32 merge_into_slot(unsigned long long* slot, u32 b1,
 
 // grid.x = query blocks of 256*R rows, grid.y = train chunks: block (x, y) scans rows [tbl[y], tbl[y+1]).  Every block
 // merges its top-2 into st.best; the last block to arrive for a query block decodes (idx + train_base, dist) and
-// restores the merge state.  Blocks with y < lead are the leaders: raised wave priority (VALU issue is arbitrated by
-// priority, then age), and after their merge they publish the exact 2nd-best distance of everything merged so far.
-// Nobody waits for them: the other blocks pick the bound up at their next share point.  (Holding the other blocks
-// back until their leaders are done was measured and lost 15-20 %: the leaders alone cannot keep the SIMDs busy.)
+// restores the merge state.  Blocks with y < lead are the leaders: short chunks at the head of the dispatch order that,
+// after their merge, publish the exact 2nd-best distance of everything merged so far.  Nobody waits for them: the other
+// blocks pick the bound up at their next share point.  Measured and dropped: holding the other blocks back until their
+// leaders are done (-15..20 %: the leaders alone cannot keep the SIMDs busy) and raising the leaders' wave priority
+// with s_setprio (no change: as the oldest waves of their SIMDs they are served first anyway).
 template <int R>
 __global__ __launch_bounds__(256) void bf_top2_kernel(const uint4* __restrict__ q, int N,
                                                       const uint4* __restrict__ t, const int* __restrict__ tbl,
-                                                      int lead, int lead_prio, bf_state st, int train_base,
+                                                      int lead, bf_state st, int train_base,
                                                       int2* __restrict__ out_idx, int2* __restrict__ out_dist) {
     __shared__ uint4 tile[2][SLAM_TILE_ROWS * 2];
     __shared__ u32 s_last;
@@ -183,11 +187,6 @@ __global__ __launch_bounds__(256) void bf_top2_kernel(const uint4* __restrict__ 
     const int lane = tid & 63, wave = tid >> 6;
     const int qbase = blockIdx.x * (256 * R) + wave * (64 * R) + lane;
     const bool leader = (int)blockIdx.y < lead;
-    if (leader) {                       // s_setprio takes an immediate
-        if (lead_prio == 3) __builtin_amdgcn_s_setprio(3);
-        else if (lead_prio == 2) __builtin_amdgcn_s_setprio(2);
-        else if (lead_prio == 1) __builtin_amdgcn_s_setprio(1);
-    }
 
     u32 qr[R][8];
 #pragma unroll
@@ -283,9 +282,11 @@ __global__ __launch_bounds__(256) void bf_top2_kernel(const uint4* __restrict__ 
         if (qi < N) {
             // bound[q] >= the final 2nd-best distance: a block whose best row is already farther than that
             // cannot contribute, so most chunk blocks skip the CAS (one 4-byte load instead)
+            // (the slot is read alongside the bound: one round trip instead of two when the merge does happen)
             const u32 g = __hip_atomic_load(&st.bound[qi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long slot = __hip_atomic_load(&st.best[qi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if ((b1[r] >> SLAM_KEY_IDX_BITS) <= g) {
-                const u32 k2 = merge_into_slot(&st.best[qi], b1[r], b2[r]);
+                const u32 k2 = merge_into_slot(&st.best[qi], slot, b1[r], b2[r]);
                 // leaders leave the exact 2nd-best distance of everything merged so far as the bound
                 if (leader && (k2 >> SLAM_KEY_IDX_BITS) < g) atomicMin(&st.bound[qi], k2 >> SLAM_KEY_IDX_BITS);
             }
@@ -373,21 +374,19 @@ struct bf_plan {
     int lead;        // leader chunks (the first `lead` entries of the table)
     int lead_rows;   // rows they cover together
     int tail;        // shrinking chunks at the end of the table
-    int lead_prio;   // s_setprio level of the leader blocks (0 = none)
 };
 
 // Tuning overrides live in the context (0 = heuristic): set through slam_bf_set_tuning, read under ctx->mu.
 extern "C" int slam_bf_set_tuning(slam_ctx* ctx, const int32_t* h_knobs, int count) {
     SLAM_REQUIRE(ctx, "slam_bf_set_tuning: null ctx");
     SLAM_REQUIRE(count >= 0 && count <= SLAM_BF_KNOBS && (h_knobs || count == 0), "bad knob array");
-    int k[SLAM_BF_KNOBS] = {0, 0, 0, 0, 0, 0};
+    int k[SLAM_BF_KNOBS] = {0, 0, 0, 0, 0};
     for (int i = 0; i < count; i++) k[i] = h_knobs[i];
     SLAM_REQUIRE(k[0] == 0 || k[0] == 1 || k[0] == 2 || k[0] == 4 || k[0] == 8, "R must be 0, 1, 2, 4 or 8");
     SLAM_REQUIRE(k[1] >= 0 && k[1] <= 64, "blocks_per_cu out of range");
     SLAM_REQUIRE(k[2] >= -1 && k[2] <= (1 << 22), "lead_rows out of range");
     SLAM_REQUIRE(k[3] >= 0 && k[3] <= (1 << 22) && k[3] % 32 == 0, "lead_chunk must be a multiple of 32 rows");
-    SLAM_REQUIRE(k[4] >= -1 && k[4] <= 3, "lead_prio must be -1 (no raise), 0 (shipped) or 1..3");
-    SLAM_REQUIRE(k[5] >= -1 && k[5] <= 4096, "tail out of range");
+    SLAM_REQUIRE(k[4] >= -1 && k[4] <= 4096, "tail out of range");
     std::lock_guard<std::mutex> g(ctx->mu);
     for (int i = 0; i < SLAM_BF_KNOBS; i++) ctx->bf_knob[i] = k[i];
     return SLAM_OK;
@@ -421,7 +420,7 @@ static void plan_uniform(const slam_ctx* ctx, int64_t N, int64_t M, int R, int b
 }
 
 // The chunk boundary table for N x M (tbl[0] = 0 ... tbl[S] = M) and the plan that goes with it.
-//   leaders:  `lead` chunks covering the first lead_rows rows; they run at raised priority and publish exact bounds.
+//   leaders:  `lead` short chunks covering the first lead_rows rows; dispatched first, they publish exact bounds.
 //             The 2nd-best distance over s rows is the 2/s quantile of a query's distances and a wave takes the update
 //             path for a row when any of its 64 lanes beats its threshold, so a block starting from the bound of s
 //             rows fires on about 128/s of its first rows.
@@ -439,8 +438,10 @@ static bf_plan make_plan(slam_ctx* ctx, int64_t N, int64_t M, std::vector<int>* 
     // ---- leaders
     int64_t lead_rows = k[2] < 0 ? 0 : k[2];
     if (k[2] == 0 && M >= 16384) {
-        lead_rows = M / 16;
-        if (lead_rows > 4096) lead_rows = 4096;
+        // measured (profiles/r02_plan_sweep.log): M/8 up to 8192 rows; 64k x 64k 1595 -> 1532 us with the tail below,
+        // the 1/8 query shard 8192 x 65536 252 -> 213 us, 20000 x 20000 181 -> 168 us
+        lead_rows = M / 8;
+        if (lead_rows > 8192) lead_rows = 8192;
     }
     lead_rows = lead_rows / 32 * 32;
     if (lead_rows + p.chunk > M) lead_rows = 0;                          // leave the rest of the grid real work
@@ -454,12 +455,10 @@ static bf_plan make_plan(slam_ctx* ctx, int64_t N, int64_t M, std::vector<int>* 
     }
     p.lead = lead_rows ? (int)((lead_rows + lead_chunk - 1) / lead_chunk) : 0;
     p.lead_rows = (int)lead_rows;
-    p.lead_prio = k[4] < 0 ? 0 : (k[4] ? k[4] : 3);
     // ---- tail
     const int64_t rest = M - lead_rows;
     int64_t n_uniform = (rest + p.chunk - 1) / p.chunk;
-    int64_t tail = k[5] < 0 ? 0 : k[5];
-    if (k[5] == 0) tail = 0;                                             // shipped choice
+    int64_t tail = k[4] < 0 ? 0 : (k[4] ? k[4] : 16);                    // shipped: 16 (8 / 16 / 32 measured alike, 4 worse)
     if (tail > 0) {
         const int64_t last_round = (slots + p.qblocks - 1) / p.qblocks;  // chunk indices in flight when the grid drains
         if (tail > last_round) tail = last_round;
@@ -591,10 +590,10 @@ static int bf_pass(slam_ctx* ctx, const void* d_query, int64_t N, const void* d_
     SLAM_HIP(hipGetLastError());
     if (int rc = slam_prof_begin(ctx)) return rc;
     switch (p.R) {
-        case 8: bf_top2_kernel<8><<<grid, block, 0, ctx->stream>>>(q, (int)N, t, d_tbl, p.lead, p.lead_prio, st, tb, oi, od); break;
-        case 4: bf_top2_kernel<4><<<grid, block, 0, ctx->stream>>>(q, (int)N, t, d_tbl, p.lead, p.lead_prio, st, tb, oi, od); break;
-        case 2: bf_top2_kernel<2><<<grid, block, 0, ctx->stream>>>(q, (int)N, t, d_tbl, p.lead, p.lead_prio, st, tb, oi, od); break;
-        default: bf_top2_kernel<1><<<grid, block, 0, ctx->stream>>>(q, (int)N, t, d_tbl, p.lead, p.lead_prio, st, tb, oi, od); break;
+        case 8: bf_top2_kernel<8><<<grid, block, 0, ctx->stream>>>(q, (int)N, t, d_tbl, p.lead, st, tb, oi, od); break;
+        case 4: bf_top2_kernel<4><<<grid, block, 0, ctx->stream>>>(q, (int)N, t, d_tbl, p.lead, st, tb, oi, od); break;
+        case 2: bf_top2_kernel<2><<<grid, block, 0, ctx->stream>>>(q, (int)N, t, d_tbl, p.lead, st, tb, oi, od); break;
+        default: bf_top2_kernel<1><<<grid, block, 0, ctx->stream>>>(q, (int)N, t, d_tbl, p.lead, st, tb, oi, od); break;
     }
     if (int rc = slam_prof_end(ctx)) return rc;
     const hipError_t e = hipGetLastError();

@@ -53,6 +53,7 @@ extern "C" int slam_ctx_create(int device, slam_ctx** out) {
     if (e == hipSuccess) e = hipEventCreate(&c->ev_start);
     if (e == hipSuccess) e = hipEventCreate(&c->ev_stop);
     if (e == hipSuccess) e = hipMalloc(&c->scratch, 4096);
+    if (e == hipSuccess) e = hipMemset(c->scratch, 0, 4096);
     if (e != hipSuccess) {
         delete c;
         return slam_set_error(SLAM_ERR_HIP, "context setup failed: %s", hipGetErrorString(e));
@@ -123,6 +124,7 @@ extern "C" int slam_free(slam_ctx* ctx, void* d_ptr) {
     }
     SLAM_HIP(hipSetDevice(ctx->device));
     SLAM_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->comm_stream) SLAM_HIP(hipStreamSynchronize(ctx->comm_stream));   // the buffer may be one side of a gather in flight
     SLAM_HIP(hipFree(d_ptr));
     return SLAM_OK;
 }
@@ -197,6 +199,17 @@ int slam_io_arena(slam_ctx* ctx, uint64_t dev_bytes, uint64_t host_bytes, void**
     }
     *dev = ctx->io_dev;
     *host = ctx->io_host;
+    return SLAM_OK;
+}
+
+extern "C" int slam_index_errors(slam_ctx* ctx, int64_t* count) {
+    SLAM_REQUIRE(ctx && count, "slam_index_errors: null argument");
+    SLAM_HIP(hipSetDevice(ctx->device));
+    unsigned int h = 0;
+    SLAM_HIP(hipMemcpyAsync(&h, slam_index_error_counter(ctx), sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    SLAM_HIP(hipMemsetAsync(slam_index_error_counter(ctx), 0, sizeof(h), ctx->stream));
+    SLAM_HIP(hipStreamSynchronize(ctx->stream));
+    *count = h;
     return SLAM_OK;
 }
 

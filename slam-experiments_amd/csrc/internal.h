@@ -19,7 +19,7 @@ struct slam_ctx {
     int num_cu = 0;
     void* bf_state_mem = nullptr;                   // matcher merge state (best/bound/arrivals), clean between launches
     int64_t bf_state_rows = 0;
-    int bf_knob[SLAM_BF_KNOBS] = {0, 0, 0, 0, 0, 0};   // matcher tuning overrides (slam_bf_set_tuning), 0 = heuristic
+    int bf_knob[SLAM_BF_KNOBS] = {0, 0, 0, 0, 0};   // matcher tuning overrides (slam_bf_set_tuning), 0 = heuristic
     void* bf_tbl_dev = nullptr;                     // chunk boundary table of the last search (device) ...
     void* bf_tbl_host = nullptr;                    // ... and its pinned host copy
     int bf_tbl_n = 0;
@@ -72,6 +72,8 @@ int slam_cross_launch(slam_ctx* ctx, const int32_t* d_fwd_idx, const int32_t* d_
 // second stream + hand-off events shared by the RCCL and the peer-copy all-gathers (p2p.hip)
 int slam_second_stream(slam_ctx* ctx);
 void slam_second_stream_destroy(slam_ctx* ctx);
+// sticky device counter of out-of-range pose / point indices met by the residual kernels (in ctx->scratch)
+static inline unsigned int* slam_index_error_counter(slam_ctx* ctx) { return (unsigned int*)((char*)ctx->scratch + 1024); }
 // event bracket around the dominant kernel when profiling is on
 int slam_prof_begin(slam_ctx* ctx);
 int slam_prof_end(slam_ctx* ctx);

@@ -69,6 +69,7 @@ __global__ __launch_bounds__(RJ_BLOCK) void reproj_rj_kernel(const double* __res
                                                              const int* __restrict__ obs_pose,
                                                              const int* __restrict__ obs_point,
                                                              const double2* __restrict__ meas, long long O, cam4 cam,
+                                                             int K, int L, unsigned int* __restrict__ index_errors,
                                                              double* __restrict__ e, double* __restrict__ Jpose,
                                                              double* __restrict__ Jpoint) {
     __shared__ double sJ[RJ_BLOCK * 12];  // 24 KiB, reused for Jpoint (12 KiB) after Jpose
@@ -78,8 +79,14 @@ __global__ __launch_bounds__(RJ_BLOCK) void reproj_rj_kernel(const double* __res
     proj_out r;
     double Rm[9];
     if (o < O) {
-        const int k = obs_pose[o], l = obs_point[o];
-        const double2 m = meas[o];
+        int k = obs_pose[o], l = obs_point[o];
+        double2 m = meas[o];
+        if ((unsigned)k >= (unsigned)K || (unsigned)l >= (unsigned)L) {
+            // misuse is reported, never dereferenced: the observation reads row 0 and comes out as NaN
+            atomicAdd(index_errors, 1u);
+            k = 0; l = 0;
+            m.x = m.y = __builtin_nan("");
+        }
         double P[12];
         const double2* pp = (const double2*)(poses + (size_t)k * 12);  // 96-B rows, 16-B aligned
 #pragma unroll
@@ -122,6 +129,7 @@ extern "C" int slam_reproj_rj_f64(slam_ctx* ctx, const double* d_poses, int64_t 
     SLAM_REQUIRE(O <= (1ll << 40), "O too large");
     if (O == 0) return SLAM_OK;
     SLAM_REQUIRE(K > 0 && L > 0, "observations given but no poses/points");
+    SLAM_REQUIRE(K <= 0x7FFFFFFF && L <= 0x7FFFFFFF, "pose / point tables are indexed by int32");
     SLAM_REQUIRE(d_poses && d_points && d_obs_pose && d_obs_point && d_meas && d_e && d_Jpose,
                  "slam_reproj_rj_f64: null device pointer");
     SLAM_REQUIRE((((uintptr_t)d_poses | (uintptr_t)d_meas | (uintptr_t)d_e | (uintptr_t)d_Jpose |
@@ -132,12 +140,12 @@ extern "C" int slam_reproj_rj_f64(slam_ctx* ctx, const double* d_poses, int64_t 
     if (int rc = slam_prof_begin(ctx)) return rc;
     if (d_Jpoint)
         reproj_rj_kernel<true><<<blocks, RJ_BLOCK, 0, ctx->stream>>>(d_poses, d_points, d_obs_pose, d_obs_point,
-                                                                      (const double2*)d_meas, O, cam, d_e, d_Jpose,
-                                                                      d_Jpoint);
+                                                                      (const double2*)d_meas, O, cam, (int)K, (int)L,
+                                                                      slam_index_error_counter(ctx), d_e, d_Jpose, d_Jpoint);
     else
         reproj_rj_kernel<false><<<blocks, RJ_BLOCK, 0, ctx->stream>>>(d_poses, d_points, d_obs_pose, d_obs_point,
-                                                                       (const double2*)d_meas, O, cam, d_e, d_Jpose,
-                                                                       nullptr);
+                                                                       (const double2*)d_meas, O, cam, (int)K, (int)L,
+                                                                       slam_index_error_counter(ctx), d_e, d_Jpose, nullptr);
     if (int rc = slam_prof_end(ctx)) return rc;
     SLAM_HIP(hipGetLastError());
     return SLAM_OK;

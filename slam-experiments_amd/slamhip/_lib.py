@@ -66,6 +66,7 @@ SIGNATURES = {
                                        c_void_p]),
     "slam_bf_match_host": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_double,
                                    c_void_p, c_void_p, c_void_p, c_void_p]),
+    "slam_index_errors": (c_int, [c_void_p, POINTER(c_int64)]),
     "slam_io_counters": (c_int, [c_void_p, POINTER(c_uint64), POINTER(c_uint64)]),
     "slam_pose_optimize_host_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double, c_double,
                                             c_double, c_double, c_int, c_int, c_double, c_double, c_void_p, c_void_p,

@@ -294,6 +294,8 @@ class KeyframeDatabase:
         self._buf = self.ctx.malloc(self._cap * DESC_BYTES)
         self.rows: list = []            # rows per keyframe, in insertion order
         self.total = 0
+        self._qbuf: Optional[DeviceBuffer] = None   # query rows + result tables, reused from query to query
+        self._qcap = 0
 
     def add(self, descriptors) -> int:
         """Append one keyframe's descriptors; returns its index (the ``imgIdx`` later results refer to)."""
@@ -325,17 +327,22 @@ class KeyframeDatabase:
         if n == 0:
             z = np.zeros((0, k), np.int32)
             return z, z.copy(), z.copy()
-        dq = DeviceDescriptors(self.ctx, q)
-        table = Top2Table(self.ctx, n)
-        try:
-            knn2_device(self.ctx, dq.buf, n, self._buf, self.total, table.idx, table.dist)
-            idx, dist = table.download()
-        finally:
-            table.free()
-            dq.free()
+        if n > self._qcap:                                   # query rows + both tables in one buffer, kept between queries
+            if self._qbuf is not None:
+                self._qbuf.free()
+            self._qcap = max(2 * n, 1024)
+            self._qbuf = self.ctx.malloc(self._qcap * (DESC_BYTES + 16))
+        dq = self._qbuf.view(0, n * DESC_BYTES).upload(q)
+        d_idx = self._qbuf.view(self._qcap * DESC_BYTES, n * 8)
+        d_dist = self._qbuf.view(self._qcap * (DESC_BYTES + 8), n * 8)
+        knn2_device(self.ctx, dq, n, self._buf, self.total, d_idx, d_dist)
+        idx, dist = d_idx.download(np.int32, (n, 2)), d_dist.download(np.int32, (n, 2))
         img, local = split_image_index(idx, self.rows)
         return (np.ascontiguousarray(img[:, :k]), np.ascontiguousarray(local[:, :k]), np.ascontiguousarray(dist[:, :k]))
 
     def free(self) -> None:
         self._buf.free()
+        if self._qbuf is not None:
+            self._qbuf.free()
+            self._qbuf, self._qcap = None, 0
         self.rows, self.total = [], 0

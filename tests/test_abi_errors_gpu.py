@@ -29,7 +29,7 @@ def test_status_codes_and_messages(gpu_ctx):
     assert lib.slam_bf_set_tuning(ctx.handle, knobs(3), 1) == -1                       # R not in {1, 2, 4, 8}
     assert lib.slam_bf_set_tuning(None, knobs(1), 1) == -1 and lib.slam_bf_set_tuning(ctx.handle, knobs(1, 0, -2), 3) == -1
     assert lib.slam_bf_set_tuning(ctx.handle, knobs(1, 0, 64, 48), 4) == -1            # leader chunk not a multiple of 32
-    assert lib.slam_bf_set_tuning(ctx.handle, None, 3) == -1 and lib.slam_bf_set_tuning(ctx.handle, knobs(*[0] * 7), 7) == -1
+    assert lib.slam_bf_set_tuning(ctx.handle, None, 3) == -1 and lib.slam_bf_set_tuning(ctx.handle, knobs(*[0] * 6), 6) == -1
     assert lib.slam_bf_set_tuning(ctx.handle, None, 0) == 0                            # reset to the shipped plan
     plan = (ctypes.c_int32 * 8)()
     assert lib.slam_bf_plan_info(ctx.handle, 65536, 65536, plan) == 0
@@ -179,3 +179,34 @@ def test_cross_check_in_one_call(gpu_ctx, n, m):
         assert c == len(eq) and np.array_equal(qi[:c], eq) and np.array_equal(ti[:c], et)
         assert np.array_equal(di[:c], np.asarray(ed, np.float32))
     dt.free()
+
+
+def test_out_of_range_indices_are_reported_not_dereferenced(gpu_ctx):
+    """slam_reproj_rj_f64 with pose / point indices outside [0, K) / [0, L): no fault, NaN outputs for exactly those
+    observations, and slam_index_errors counts them (then clears)."""
+    lib, ctx = gpu_ctx.lib, gpu_ctx
+    K, L, O = 3, 10, 700
+    rng = np.random.default_rng(5)
+    poses = np.tile(np.eye(4)[:3, :4].reshape(12), (K, 1))
+    points = np.c_[rng.uniform(-1, 1, (L, 2)), rng.uniform(4, 9, L)]
+    op = rng.integers(0, K, O).astype(np.int32)
+    ol = rng.integers(0, L, O).astype(np.int32)
+    bad = np.array([0, 5, 64, 255, 256, 699])
+    op[bad[:3]] = [K, -1, 2**31 - 1]
+    ol[bad[3:]] = [L, -7, 1 << 30]
+    meas = rng.uniform(0, 700, (O, 2))
+    d = [ctx.upload(a) for a in (poses, points, op, ol, meas)]
+    e, Jp, Jq = ctx.malloc(O * 16), ctx.malloc(O * 96), ctx.malloc(O * 48)
+    cnt = ctypes.c_int64(-1)
+    assert lib.slam_index_errors(ctx.handle, ctypes.byref(cnt)) == 0          # clear whatever earlier tests left
+    for with_point in (True, False):
+        assert lib.slam_reproj_rj_f64(ctx.handle, d[0].ptr, K, d[1].ptr, L, d[2].ptr, d[3].ptr, d[4].ptr, O, 458.0, 457.0,
+                                      367.0, 248.0, e.ptr, Jp.ptr, Jq.ptr if with_point else None) == 0
+        he = e.download(np.float64, (O, 2))
+        isbad = np.zeros(O, bool)
+        isbad[bad] = True
+        assert np.isnan(he[isbad]).all() and np.isfinite(he[~isbad]).all()
+        assert lib.slam_index_errors(ctx.handle, ctypes.byref(cnt)) == 0 and cnt.value == len(bad)
+        assert lib.slam_index_errors(ctx.handle, ctypes.byref(cnt)) == 0 and cnt.value == 0
+    for b in (*d, e, Jp, Jq):
+        b.free()

@@ -38,7 +38,7 @@ def test_ladder_ties_short_train_through_hip(gpu_ctx):
         tab = slamhip.Top2Table(gpu_ctx, dq.rows)
         try:
             for R, bpc in ((0, 0), (1, 1), (2, 4), (4, 16), (8, 2)):
-                gpu_ctx.set_tuning(R=R, blocks_per_cu=bpc, lead_rows=32 * (R % 3), lead_prio=R % 4 - 1, tail=bpc)
+                gpu_ctx.set_tuning(R=R, blocks_per_cu=bpc, lead_rows=32 * (R % 3), tail=bpc)
                 slamhip.knn2_device(gpu_ctx, dq.buf, dq.rows, dt.buf, dt.rows, tab.idx, tab.dist)
                 idx, dist = tab.download()
                 assert idx.tolist() == g["idx"] and dist.tolist() == g["dist"], (name, R, bpc)

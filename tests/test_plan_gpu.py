@@ -34,10 +34,10 @@ def test_every_plan_shape_is_bit_identical(gpu_ctx, n, m):
     try:
         for R in (1, 2, 4, 8):
             for lead_rows, lead_chunk in ((-1, 0), (256, 0), (512, 64), (1024, 32), (0, 0)):
-                for bpc, prio, tail in ((0, 0, 0), (8, 1, 5), (0, 1, 64), (32, 0, 3)):
-                    ctx.set_tuning(R=R, blocks_per_cu=bpc, lead_rows=lead_rows, lead_chunk=lead_chunk, lead_prio=prio, tail=tail)
+                for bpc, tail in ((0, 0), (8, 5), (0, 64), (32, -1)):
+                    ctx.set_tuning(R=R, blocks_per_cu=bpc, lead_rows=lead_rows, lead_chunk=lead_chunk, tail=tail)
                     idx, dist = _search(ctx, dq, n, dt, m, tab)
-                    assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist), (R, lead_rows, lead_chunk, bpc, prio, tail)
+                    assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist), (R, lead_rows, lead_chunk, bpc, tail)
     finally:
         ctx.set_tuning()
         for o in (tab, dq, dt):
@@ -51,7 +51,7 @@ def test_plan_tables_and_degenerate_inputs(gpu_ctx):
     from oracle import oracle
 
     ctx = gpu_ctx
-    for m, lead in ((200, 0), (16383, 0), (16384, 1024), (65536, 4096), (1 << 20, 4096)):
+    for m, lead in ((200, 0), (16383, 0), (16384, 2048), (65536, 8192), (1 << 20, 8192)):
         p = ctx.plan_info(8192, m)
         assert p["lead_rows"] == lead and (p["lead_chunks"] > 0) == (lead > 0), (m, p)
     try:
@@ -72,7 +72,7 @@ def test_plan_tables_and_degenerate_inputs(gpu_ctx):
             t[rows] = q                                         # every query has an exact copy in / behind the leader rows
         for wait in (0, 1):
             try:
-                ctx.set_tuning(lead_prio=wait - 1, tail=7 * wait)
+                ctx.set_tuning(lead_rows=-wait, tail=7 * wait)
                 idx, dist = slamhip.knn_match_arrays(q, t, 2, ctx=ctx)
             finally:
                 ctx.set_tuning()

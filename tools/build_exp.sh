@@ -1,0 +1,52 @@
+#!/bin/bash
+# Builds the two experiment variants of libslamhip.so used by tools/trace_probe.py and tools/exp_probe.py into
+# tools/exp/ (development aid; nothing in the product or the tests loads them).  Both are the shipped sources with a
+# small patch applied to a temporary copy of bf_hamming.hip:
+#   libslamhip_trace.so      every block stamps wall_clock64() at start / after the prologue / after the scan / at the end
+#   libslamhip_keepbound.so  the last arriver leaves the final 2nd-best distance in bound[] instead of restoring it
+#   libslamhip_count.so      counts, per launch, the 16-row groups and the single rows that take the update path
+set -euo pipefail
+ROOT="$(cd "$(dirname "$0")/.." && pwd)"
+SRC="$ROOT/slam-experiments_amd/csrc"
+OUT="$ROOT/tools/exp"
+TMP="$(mktemp -d)"
+mkdir -p "$OUT"
+make -C "$SRC" -j8 all >/dev/null
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$ROOT/include -I/opt/rocm/include -I$SRC -fvisibility=hidden -DSLAM_BUILD"
+OBJS=$(ls "$ROOT"/slam-experiments_amd/lib/obj/*.o | grep -v bf_hamming)
+
+python3 - "$SRC/bf_hamming.hip" "$TMP/bf_trace.hip" "$TMP/bf_keep.hip" "$TMP/bf_count.hip" <<'EOF'
+import sys
+src = open(sys.argv[1]).read()
+T = '    if (tid == 0 && g_trace) { g_trace[4*(blockIdx.y*gridDim.x+blockIdx.x)+%d] = wall_clock64(); }\n'
+s = src.replace('    const bool leader = (int)blockIdx.y < lead;\n', T % 0 + '    const bool leader = (int)blockIdx.y < lead;\n', 1)
+s = s.replace('    int buf = 0;\n', T % 1 + '    int buf = 0;\n', 1)
+s = s.replace('    // ---- epilogue: merge,', T % 2 + '    // ---- epilogue: merge,', 1)
+s = s.replace('    if (!s_last) return;\n', T % 3 + '    if (!s_last) return;\n', 1)
+s = s.replace('typedef uint32_t u32;', 'typedef uint32_t u32;\n__device__ unsigned long long* g_trace = nullptr;\n'
+              'extern "C" __attribute__((visibility("default"))) int slam_exp_set_trace(void* p) '
+              '{ return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &p, sizeof(p)); }', 1)
+assert s.count('g_trace[') == 4, "trace hooks did not apply: the kernel source changed"
+open(sys.argv[2], 'w').write(s)
+old = '__hip_atomic_store(&st.bound[qi], 0x7F7F7F7Fu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);'
+assert src.count(old) == 1, "keep-bound hook did not apply: the kernel source changed"
+open(sys.argv[3], 'w').write(src.replace(old, '__hip_atomic_store(&st.bound[qi], k2 == SLAM_KEY_NONE ? 0x7F7F7F7Fu : '
+                                              '(k2 >> SLAM_KEY_IDX_BITS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);'))
+g = '    if (__builtin_expect(__ballot((int)m >= 0) != 0ull, 0)) {\n'
+r = '            if (U > 1 && __ballot((int)mu >= 0) == 0ull) continue;\n'
+assert src.count(g) == 1 and src.count(r) == 1, "count hooks did not apply: the kernel source changed"
+c = src.replace(g, g + '        if (g_fire && (threadIdx.x & 63) == 0) atomicAdd(&g_fire[U > 1 ? 0 : 2], 1ull);\n')
+c = c.replace(r, r + '            if (g_fire && (threadIdx.x & 63) == 0) atomicAdd(&g_fire[1], 1ull);\n')
+c = c.replace('typedef uint32_t u32;', 'typedef uint32_t u32;\n__device__ unsigned long long* g_fire = nullptr;\n'
+              'extern "C" __attribute__((visibility("default"))) int slam_exp_set_fire(void* p) '
+              '{ return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_fire), &p, sizeof(p)); }', 1)
+open(sys.argv[4], 'w').write(c)
+EOF
+for v in trace keep count; do
+    /opt/rocm/bin/hipcc $FLAGS -c "$TMP/bf_$v.hip" -o "$TMP/bf_$v.o"
+done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libslamhip_trace.so" "$TMP/bf_trace.o" $OBJS -ldl
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libslamhip_keepbound.so" "$TMP/bf_keep.o" $OBJS -ldl
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libslamhip_count.so" "$TMP/bf_count.o" $OBJS -ldl
+rm -rf "$TMP"
+ls -la "$OUT"

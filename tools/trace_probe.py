@@ -1,7 +1,9 @@
 """Per-block timeline of one top-2 launch (development aid; needs the experiment build tools/exp/libslamhip_trace.so,
 which stamps wall_clock64() at block start / after the prologue / after the scan / at the end).
 
-    python tools/trace_probe.py NxM [seed_rows] [blocks_per_cu]
+    python tools/trace_probe.py NxM [lead_rows] [blocks_per_cu] [tail]        (0 = shipped choice, -1 = off)
+
+Build the experiment library first: tools/build_exp.sh
 """
 import ctypes
 import os
@@ -18,12 +20,11 @@ _lib.LIB_PATH = os.path.join(ROOT, "tools", "exp", "libslamhip_trace.so")
 n, m = (int(v) for v in sys.argv[1].split("x"))
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else -1
 bpc = int(sys.argv[3]) if len(sys.argv) > 3 else 0
-prio = int(sys.argv[4]) if len(sys.argv) > 4 else 0
-tail = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+tail = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 ctx = slamhip.Context(0)
 lib, h = ctx.lib, ctx.handle
 lib.slam_exp_set_trace.argtypes = [ctypes.c_void_p]
-ctx.set_tuning(blocks_per_cu=bpc, lead_rows=seed, lead_prio=prio, tail=tail)
+ctx.set_tuning(blocks_per_cu=bpc, lead_rows=seed, tail=tail)
 plan = (ctypes.c_int32 * 8)()
 lib.slam_bf_plan_info(h, n, m, plan)
 blocks = plan[1] * plan[3]
