@@ -1,8 +1,8 @@
 """Summarise the two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) over bench.py into profiles/r02_hbm_counters.json.
 
 Usage (on the GPU box, each pass on its own as MI355X_MICROARCH.md prescribes; tools/profile_r02.sh does all of it):
-  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o fetch -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-pipelined
-  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o write -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-pipelined
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o fetch -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o write -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline
   python tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write > profiles/r02_hbm_counters.json
 
 The summary is stamped with the hash of the kernel sources it was collected on; bench.py prints `traffic: null` with
@@ -57,7 +57,7 @@ try:
 except OSError:
     head = ""
 out = {
-    "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE  and, separately,  --pmc WRITE_SIZE  -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-pipelined",
+    "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE  and, separately,  --pmc WRITE_SIZE  -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline",
     "head": head or "unknown (no git on the GPU box: see the commit that added this file)",
     "source_sha": {n: sha(n) for n in ("bf_hamming.hip", "reproj.hip")},
     "units": "raw counter values are KB per launch",

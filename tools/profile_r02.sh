@@ -8,12 +8,12 @@ OUT=gpurun_out/r02
 mkdir -p $OUT
 export TMPDIR=/tmp
 PY=python3
-B="bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-pipelined"
+B="bench.py --steps 5 --warmup 1 --no-cpu-baseline"
 
 $PY bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err
 echo "bench done: $(cut -c1-160 $OUT/bench_n1.json)"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_default -o stats -- $PY bench.py > $OUT/bench_default_under_rocprof.json 2> $OUT/stats_default.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_long -o stats -- $PY bench.py --steps 400 --warmup 20 --no-reproj --no-pipelined --no-cpu-baseline > $OUT/bench_long_under_rocprof.json 2> $OUT/stats_long.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_long -o stats -- $PY bench.py --steps 400 --warmup 20 --no-reproj --no-cpu-baseline > $OUT/bench_long_under_rocprof.json 2> $OUT/stats_long.err
 echo "kernel stats done"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o fetch -- $PY $B > /dev/null 2> $OUT/pmc_fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o write -- $PY $B > /dev/null 2> $OUT/pmc_write.err
@@ -31,3 +31,6 @@ find $OUT -name "*kernel_stats.csv" | head
 # the trace databases are large; keep the csv summaries only
 find $OUT -name "*.db" -delete 2>/dev/null
 du -sh $OUT
+$PY bench.py --pipelined --no-reproj --no-cpu-baseline > $OUT/bench_pipelined.json 2> $OUT/bench_pipelined.err
+$PY tools/fire_probe.py > $OUT/update_path_share.log 2>&1
+$PY tools/ba_time.py > $OUT/ba_schur_timing.log 2>&1
