@@ -53,6 +53,9 @@ OPS_PER_PAIR = 16                 # 8 v_xor + 8 v_bcnt per 256-bit pair (algorit
 # measured issue cost (tools/ubench/valu_rate.hip): v_xor 2 cycles, v_bcnt 4 cycles per wave64
 CYCLES_PER_PAIRSTEP = 8 * 2 + 8 * 4
 ROW_LOOP_CYCLES = 54.8            # measured: isolated [lgkmcnt wait, 8 v_xor, 8 v_bcnt, 2 ds_read_b128] row loop, 2.38 GHz
+# sustained issue cost of the two instructions themselves at 8 waves/SIMD (tools/ubench/class_order.hip,
+# profiles/r02_ubench_class_order.log): v_xor_b32 2.54, v_bcnt_u32_b32 4.48 cycles per wave64
+OP_RATE_CYCLES_PER_ROW = 8 * 2.54 + 8 * 4.48
 SPIN_UP_PASSES = 24               # the GPU needs ~10 passes (~20 ms) of load before DVFS reaches its steady clock (tools/ramp.py)
 HBM_COUNTERS = os.path.join(ROOT, "profiles", "r02_hbm_counters.json")
 KERNEL_SOURCES = {"bf_top2_kernel": "bf_hamming.hip", "reproj_rj_kernel": "reproj.hip"}
@@ -382,6 +385,8 @@ def main() -> int:
                              "issue_floor_ms": cyc_floor_ms, "frac_of_issue_floor": cyc_floor_ms / kernel_ms,
                              "issue_model": "v_xor 2 cyc + v_bcnt 4 cyc per wave64 (measured), 2.4 GHz",
                              # tools/ubench/ring_probe.hip: the bare row loop (wait, 16 VALU, 2 ds_read_b128) at 8 waves/SIMD
+                             "sustained_op_rate_cycles_per_row": OP_RATE_CYCLES_PER_ROW,
+                             "frac_of_sustained_op_rates": (local_pairs / 64 * OP_RATE_CYCLES_PER_ROW / (256 * 4) / 2.4e9 * 1e3) / kernel_ms,
                              "isolated_row_loop_cycles": ROW_LOOP_CYCLES,
                              "frac_of_isolated_row_loop": (local_pairs / 64 * ROW_LOOP_CYCLES / (256 * 4) / 2.38e9 * 1e3) / kernel_ms}},
         }

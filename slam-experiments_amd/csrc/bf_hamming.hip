@@ -37,10 +37,13 @@
 //     the last block to arrive for a query block (agent-scope ticket) decodes
 //     the slots to (int32 idx, int32 dist) and restores the merge state, so a
 //     call is ONE kernel: no memset, no partial tables, no merge kernel.
-// Measured VALU issue costs on gfx950 (tools/ubench/valu_rate.hip): v_xor 2
-// cycles per wave64, v_bcnt / v_min / v_med3 / v_cmp / shifts 4 cycles, so a
-// pair costs >= 8*2 + 8*4 = 48 SIMD cycles; SGPR or DPP operands make v_xor a
-// 4-cycle op, which is why train rows come from LDS into VGPRs.
+// Measured VALU issue costs on gfx950 (tools/ubench/valu_rate.hip): v_xor is in
+// the 2-cycle class per wave64, v_bcnt / v_min / v_med3 / v_cmp / shifts in the
+// 4-cycle class, so a pair costs >= 8*2 + 8*4 = 48 SIMD cycles nominally; their
+// SUSTAINED rates at 8 waves/SIMD are 2.54 and 4.48 cycles (class_order.hip),
+// i.e. 56.2 cycles per row, which is what this kernel runs at.  SGPR or DPP
+// operands make v_xor a 4-cycle op, which is why train rows come from LDS into
+// VGPRs.
 #include "internal.h"
 #include <stdio.h>
 #include <vector>
@@ -64,11 +67,48 @@ __device__ __forceinline__ u32 bcnt_acc(u32 x, u32 acc) {
 }
 __device__ __forceinline__ u32 umed3(u32 a, u32 b, u32 c) { return max(min(a, b), min(max(a, b), c)); }
 
+// LDS byte address of a __shared__ object, and a 16-byte LDS read at address + constant (becomes the offset: field)
+__device__ __forceinline__ u32 lds_addr(const uint4* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (u32)(uintptr_t)(const __attribute__((address_space(3))) uint4*)p;
+#else
+    return 0;
+#endif
+}
+__device__ __forceinline__ uint4 lds_read16(u32 addr, int byte_offset) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((address_space(3))) const uint4 lds_u4;
+    return *(lds_u4*)(uintptr_t)(addr + byte_offset);
+#else
+    return make_uint4(0, 0, 0, 0);
+#endif
+}
+
 // distances of one train row (a = words 0-3, b = words 4-7) to the lane's R queries, biased:
 // acc[r] = 2^31 - th[r] + d  =>  d < th[r]  <=>  acc[r] < 2^31 (sign bit clear)
+//
+// R = 1 issues the row as ONE block: the eight v_xor first (each overwrites its train word, which is dead afterwards,
+// so no extra registers), then the eight accumulating v_bcnt.  On gfx950 a 2-cycle-class op that alternates with
+// 4-cycle-class ops is issued at the 4-cycle rate in a synthetic loop: the alternating order (what the compiler emits
+// from the C++ form) costs 4.45 cycles per instruction, as much as v_bcnt alone, where eight of a kind followed by eight
+// of the other cost 3.78 (tools/ubench/class_order.hip, profiles/r02_ubench_class_order.log).  In the kernel, where
+// eight waves with drifting phases share the SIMD, both orders run alike (1543 vs 1558 us): the sustained rates of the
+// two instructions themselves, 2.54 and 4.48 cycles, are what bounds it (8 x 2.54 + 8 x 4.48 = 56.2 cycles per row;
+// the kernel runs at 56.3-56.6).  The block form stays because it fixes the order against compiler changes.
 template <int R>
-__device__ __forceinline__ void row_acc(const u32 (&q)[R][8], const uint4 a, const uint4 b, const u32 (&init)[R],
+__device__ __forceinline__ void row_acc(const u32 (&q)[R][8], uint4 a, uint4 b, const u32 (&init)[R],
                                         u32 (&acc)[R]) {
+    if constexpr (R == 1) {
+        asm("v_xor_b32 %1, %9, %1\n\tv_xor_b32 %2, %10, %2\n\tv_xor_b32 %3, %11, %3\n\tv_xor_b32 %4, %12, %4\n\t"
+            "v_xor_b32 %5, %13, %5\n\tv_xor_b32 %6, %14, %6\n\tv_xor_b32 %7, %15, %7\n\tv_xor_b32 %8, %16, %8\n\t"
+            "v_bcnt_u32_b32 %0, %1, %17\n\tv_bcnt_u32_b32 %0, %2, %0\n\tv_bcnt_u32_b32 %0, %3, %0\n\t"
+            "v_bcnt_u32_b32 %0, %4, %0\n\tv_bcnt_u32_b32 %0, %5, %0\n\tv_bcnt_u32_b32 %0, %6, %0\n\t"
+            "v_bcnt_u32_b32 %0, %7, %0\n\tv_bcnt_u32_b32 %0, %8, %0"
+            : "=v"(acc[0]), "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w), "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(b.w)
+            : "v"(q[0][0]), "v"(q[0][1]), "v"(q[0][2]), "v"(q[0][3]), "v"(q[0][4]), "v"(q[0][5]), "v"(q[0][6]),
+              "v"(q[0][7]), "v"(init[0]));
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < R; r++) acc[r] = bcnt_acc(q[r][0] ^ a.x, init[r]);
 #pragma unroll
@@ -180,7 +220,7 @@ __global__ __launch_bounds__(256) void bf_top2_kernel(const uint4* __restrict__ 
                                                       const uint4* __restrict__ t, const int* __restrict__ tbl,
                                                       int lead, bf_state st, int train_base,
                                                       int2* __restrict__ out_idx, int2* __restrict__ out_dist) {
-    __shared__ uint4 tile[2][SLAM_TILE_ROWS * 2];
+    __shared__ uint4 tile[2][SLAM_TILE_ROWS * 2 + 4];
     __shared__ u32 s_last;
     u32* __restrict__ bound = st.bound;
     const int tid = threadIdx.x;
@@ -231,14 +271,13 @@ __global__ __launch_bounds__(256) void bf_top2_kernel(const uint4* __restrict__ 
         share_bound<R>(bound, qbase, N, b2, init);
         const int cnt = __builtin_amdgcn_readfirstlane(min(SLAM_TILE_ROWS, t1 - tb));
         const uint4* tp = tile[buf];
-        // software pipeline: the row after next is read from LDS while the current one is computed
-        // (the last prefetch wraps inside the tile and is discarded).  Measured: letting the compiler
-        // batch a whole group's reads behind immediate offsets is 6 % slower than this rolling form.
+        // software pipeline: the next row is read from LDS while the current one is computed (the last
+        // read-ahead lands in the tile's padding and is discarded).  Measured: letting the compiler batch
+        // a whole group's reads behind immediate offsets is 6 % slower than this rolling form.
         int j = 0;
         uint4 a0 = tp[0], c0 = tp[1];
         constexpr int U = SLAM_GROUP_PAIRS / R;   // 16 rows at R = 1 (58 VGPRs, still 8 waves/SIMD)
         static_assert(U >= 2 && U % 2 == 0, "row pipeline handles rows in pairs");
-        constexpr int WRAP = 2 * SLAM_TILE_ROWS - 1;
         // A block starts with no threshold of its own, so in its first tile nearly every group takes the
         // update path; there the bound is re-read after 16, 32, 64 and 128 rows (what the sibling blocks
         // have scanned meanwhile tightens it), later once per tile.
@@ -247,13 +286,22 @@ __global__ __launch_bounds__(256) void bf_top2_kernel(const uint4* __restrict__ 
             const int lim = min(seg_end, cnt);
             for (; j + U <= lim; j += U) {
                 u32 acc[U][R];
+                // rows are read through ONE running LDS address in a VGPR plus immediate offsets (the tile is padded by two
+                // rows so the read-ahead needs no wrap); the empty asm after every row block ties that address to the
+                // row's result, so the reads stay where they are written - rolling, one row ahead - instead of being
+                // batched by the scheduler (batched: 67 VGPRs, 7 waves/SIMD).  Against per-read scalar address arithmetic
+                // + v_mov from SGPR this saves ~1.5 VALU and ~8 SALU instructions per row: no change where the VALU is
+                // saturated (64k x 64k), 3-12 % on latency-bound sizes (4096 x 4096 30.5 -> 26.8 us).
+                u32 base = lds_addr(tp + 2 * j);
 #pragma unroll
                 for (int u = 0; u < U; u += 2) {
-                    const uint4 a1 = tp[(2 * (j + u) + 2) & WRAP], c1 = tp[(2 * (j + u) + 3) & WRAP];
+                    const uint4 a1 = lds_read16(base, (2 * u + 2) * 16), c1 = lds_read16(base, (2 * u + 3) * 16);
                     row_acc<R>(qr, a0, c0, init, acc[u]);
-                    a0 = tp[(2 * (j + u) + 4) & WRAP];
-                    c0 = tp[(2 * (j + u) + 5) & WRAP];
+                    asm volatile("" : "+v"(base) : "v"(acc[u][0]));
+                    a0 = lds_read16(base, (2 * u + 4) * 16);
+                    c0 = lds_read16(base, (2 * u + 5) * 16);
                     row_acc<R>(qr, a1, c1, init, acc[u + 1]);
+                    asm volatile("" : "+v"(base) : "v"(acc[u + 1][0]));
                 }
                 filter_update<R, U>(acc, (u32)(tb + j), b1, b2, init);
             }

@@ -131,6 +131,14 @@ class BruteForceFeatureMatcher(FeatureMatcher):
             qi, ti, dist = _m.match_arrays(source_descriptors, query_descriptors, dist_threshold, cache=self._cache)
         return MatchList(qi, ti, dist)
 
+    def close(self) -> None:
+        """Release the device buffers that hold the last frame's descriptors (optional: they are two small
+        allocations that otherwise live as long as the process-wide context)."""
+        with self._lock:
+            if self._cache is not None:
+                self._cache.free()
+                self._cache = None
+
     # ---- array-level extensions (not in the reference) -----------------------
     def match_arrays(self, source_descriptors, query_descriptors, dist_threshold: Optional[float] = None):
         return _m.match_arrays(source_descriptors, query_descriptors, dist_threshold)

@@ -10,6 +10,12 @@ for p in (PKG, ROOT):
         sys.path.insert(0, p)
 
 
+if os.environ.get("SLAMHIP_TEST_LIB"):      # development aid: run the suite against an experiment build (tools/build_exp.sh)
+    from slamhip import _lib as _slamhip_lib
+
+    _slamhip_lib.LIB_PATH = os.path.abspath(os.environ["SLAMHIP_TEST_LIB"])
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
 

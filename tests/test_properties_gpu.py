@@ -100,6 +100,32 @@ def test_sampled_rows_against_the_oracle(gpu_ctx, base):
     assert np.array_equal(idx[sel], ridx) and np.array_equal(dist[sel], rdist)
 
 
+def test_strided_readonly_and_oddly_typed_inputs(gpu_ctx):
+    """What callers may hand over besides fresh contiguous arrays: row-strided and column-sliced views, Fortran order,
+    read-only arrays, lists of rows (Frame.get_descriptors stacks a Python list, primitives.py:200-205), and wrong
+    dtypes / widths, which must be refused before the FFI call."""
+    import slamhip
+    from oracle import oracle
+
+    rng = np.random.default_rng(11)
+    big_q = rng.integers(0, 256, (600, 40), dtype=np.uint8)
+    big_t = rng.integers(0, 256, (900, 32), dtype=np.uint8)
+    q = big_q[::2, 4:36]                                       # every other row, columns 4..35: neither contiguous
+    t = np.asfortranarray(big_t[::-1])                         # reversed rows, column-major
+    t.setflags(write=False)
+    ei, ed = oracle.bf_knn_c(np.ascontiguousarray(q), np.ascontiguousarray(t), 2, threads=4)
+    gi, gd = slamhip.knn_match_arrays(q, t, 2, ctx=gpu_ctx)
+    assert np.array_equal(gi, ei) and np.array_equal(gd, ed)
+    mq, mt, md = slamhip.match_arrays([row for row in t], [row for row in q], 70.0, ctx=gpu_ctx)   # lists of rows
+    eq, et, edd = oracle.bf_match_c(np.ascontiguousarray(t), np.ascontiguousarray(q), 70.0)
+    assert np.array_equal(mq, eq) and np.array_equal(mt, et) and np.array_equal(md, edd)
+    for bad in (q.astype(np.int32), q.astype(np.float32), np.zeros((5, 31), np.uint8), np.zeros((5, 32, 1), np.uint8)):
+        with pytest.raises(ValueError):
+            slamhip.knn_match_arrays(bad, t, 2, ctx=gpu_ctx)
+        with pytest.raises(ValueError):
+            slamhip.match_arrays(t, bad, ctx=gpu_ctx)
+
+
 def test_ratio_filter_and_cross_check_properties_4k(gpu_ctx):
     """BASELINE configs[1] (4096 x 4096, knn=2 + ratio 0.75): the device-side selections against the oracle on every
     row, and crossCheck's symmetry: swapping the roles of query and train returns the same pairs, transposed."""
