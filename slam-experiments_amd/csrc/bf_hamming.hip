@@ -557,6 +557,7 @@ extern "C" int slam_bf_plan_info(slam_ctx* ctx, int64_t N, int64_t M, int32_t* h
 
 // merge state for up to N queries, kept clean between launches (see bf_state), followed by the chunk boundary table
 #define SLAM_BF_TBL_MAX 65536   // entries; grid.y <= 65535
+// (SLAM_BF_TBL_RING slots of SLAM_BF_TBL_SLOT entries + one slot of SLAM_BF_TBL_MAX: internal.h)
 static int bf_state_fill(slam_ctx* ctx) {
     char* p = (char*)ctx->bf_state_mem;
     const size_t rows = (size_t)ctx->bf_state_rows, blocks = (rows + 255) / 256;
@@ -588,24 +589,62 @@ static int bf_state_get(slam_ctx* ctx, int64_t N, bf_state* out) {
     return SLAM_OK;
 }
 
-// the boundary table on the device: re-uploaded only when it differs from the one the last search used
+// The boundary table on the device.  A search whose table equals the previous one reuses it (back-to-back searches of
+// one shape upload nothing).  Otherwise the table goes into the next slot of a small ring of (pinned host, device) slot
+// pairs with one asynchronous copy and NO synchronisation: frame-sized searches change shape on every frame
+// (frontend.py:181-187 matches whatever ORB found), and crossCheck alternates N x M with M x N.  The device side of a
+// slot is safe by stream order (the copy into it queues behind every launch that read it); the pinned host side is
+// rewritten by the CPU, so an event recorded behind each upload is checked before the slot's next turn,
+// SLAM_BF_TBL_RING changes of shape later (it has long fired).
+// Tables with more than SLAM_BF_TBL_SLOT entries (train sets cut into > 4095 chunks) take the one big slot, which
+// is rewritten behind a stream synchronisation.
 static int bf_table_get(slam_ctx* ctx, const std::vector<int>& tbl, const int** d_tbl) {
     std::lock_guard<std::mutex> g(ctx->mu);
-    SLAM_REQUIRE(tbl.size() <= SLAM_BF_TBL_MAX, "train set needs %zu chunks, more than one launch can index", tbl.size() - 1);
+    const size_t n = tbl.size();
+    SLAM_REQUIRE(n <= SLAM_BF_TBL_MAX, "train set needs %zu chunks, more than one launch can index", n - 1);
     if (!ctx->bf_tbl_dev) {
-        SLAM_HIP(hipMalloc(&ctx->bf_tbl_dev, SLAM_BF_TBL_MAX * sizeof(int)));
-        SLAM_HIP(hipHostMalloc(&ctx->bf_tbl_host, SLAM_BF_TBL_MAX * sizeof(int), hipHostMallocDefault));
-        ctx->bf_tbl_n = 0;
+        const size_t ints = (size_t)SLAM_BF_TBL_RING * SLAM_BF_TBL_SLOT + SLAM_BF_TBL_MAX;
+        SLAM_HIP(hipMalloc(&ctx->bf_tbl_dev, ints * sizeof(int)));
+        SLAM_HIP(hipHostMalloc(&ctx->bf_tbl_host, ints * sizeof(int), hipHostMallocDefault));
+        for (int i = 0; i <= SLAM_BF_TBL_RING; i++) {
+            ctx->bf_tbl_n[i] = 0;
+            ctx->bf_tbl_busy[i] = false;
+            if (i < SLAM_BF_TBL_RING) SLAM_HIP(hipEventCreateWithFlags(&ctx->bf_tbl_ev[i], hipEventDisableTiming));
+        }
+        ctx->bf_tbl_cur = 0;
     }
     int* host = (int*)ctx->bf_tbl_host;
-    if (ctx->bf_tbl_n != (int)tbl.size() || memcmp(host, tbl.data(), tbl.size() * sizeof(int)) != 0) {
-        // the previous table may still be read by a queued launch, and the staging copy by a queued upload
-        SLAM_HIP(hipStreamSynchronize(ctx->stream));
-        memcpy(host, tbl.data(), tbl.size() * sizeof(int));
-        ctx->bf_tbl_n = (int)tbl.size();
-        SLAM_HIP(hipMemcpyAsync(ctx->bf_tbl_dev, host, tbl.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    int* dev = (int*)ctx->bf_tbl_dev;
+    const bool big = n > SLAM_BF_TBL_SLOT;
+    int slot = big ? SLAM_BF_TBL_RING : ctx->bf_tbl_cur;
+    if (!big)   // any slot that still holds this table will do (shapes that alternate, e.g. crossCheck's two searches)
+        for (int i = 0; i < SLAM_BF_TBL_RING; i++)
+            if (ctx->bf_tbl_n[i] == (int)n && memcmp(host + (size_t)i * SLAM_BF_TBL_SLOT, tbl.data(), n * sizeof(int)) == 0) {
+                slot = i;
+                break;
+            }
+    size_t off = big ? (size_t)SLAM_BF_TBL_RING * SLAM_BF_TBL_SLOT : (size_t)slot * SLAM_BF_TBL_SLOT;
+    if (ctx->bf_tbl_n[slot] != (int)n || memcmp(host + off, tbl.data(), n * sizeof(int)) != 0) {
+        if (big) {
+            SLAM_HIP(hipStreamSynchronize(ctx->stream));      // a queued launch may still read the big slot
+        } else {
+            slot = (ctx->bf_tbl_cur + 1) % SLAM_BF_TBL_RING;
+            off = (size_t)slot * SLAM_BF_TBL_SLOT;
+            if (ctx->bf_tbl_busy[slot]) {                      // its last upload: SLAM_BF_TBL_RING changes of shape ago
+                SLAM_HIP(hipEventSynchronize(ctx->bf_tbl_ev[slot]));
+                ctx->bf_tbl_busy[slot] = false;
+            }
+            ctx->bf_tbl_cur = slot;
+        }
+        memcpy(host + off, tbl.data(), n * sizeof(int));
+        ctx->bf_tbl_n[slot] = (int)n;
+        SLAM_HIP(hipMemcpyAsync(dev + off, host + off, n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        if (!big) {
+            SLAM_HIP(hipEventRecord(ctx->bf_tbl_ev[slot], ctx->stream));
+            ctx->bf_tbl_busy[slot] = true;
+        }
     }
-    *d_tbl = (const int*)ctx->bf_tbl_dev;
+    *d_tbl = dev + off;
     return SLAM_OK;
 }
 

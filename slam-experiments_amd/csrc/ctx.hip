@@ -74,7 +74,10 @@ extern "C" int slam_ctx_destroy(slam_ctx* ctx) {
     if (ctx->io_dev) (void)hipFree(ctx->io_dev);
     if (ctx->io_host) (void)hipHostFree(ctx->io_host);
     if (ctx->bf_state_mem) (void)hipFree(ctx->bf_state_mem);
-    if (ctx->bf_tbl_dev) (void)hipFree(ctx->bf_tbl_dev);
+    if (ctx->bf_tbl_dev) {
+        (void)hipFree(ctx->bf_tbl_dev);
+        for (int i = 0; i < SLAM_BF_TBL_RING; i++) (void)hipEventDestroy(ctx->bf_tbl_ev[i]);
+    }
     if (ctx->bf_tbl_host) (void)hipHostFree(ctx->bf_tbl_host);
     if (ctx->prof_ev) {
         for (int i = 0; i < 2 * slam_ctx::PROF_MAX; i++) (void)hipEventDestroy(ctx->prof_ev[i]);

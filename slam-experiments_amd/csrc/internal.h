@@ -8,6 +8,9 @@
 #include <mutex>
 #include "slamhip.h"
 
+#define SLAM_BF_TBL_RING 8
+#define SLAM_BF_TBL_SLOT 4096
+
 struct slam_ctx {
     int device = -1;
     hipStream_t stream = nullptr;
@@ -20,9 +23,13 @@ struct slam_ctx {
     void* bf_state_mem = nullptr;                   // matcher merge state (best/bound/arrivals), clean between launches
     int64_t bf_state_rows = 0;
     int bf_knob[SLAM_BF_KNOBS] = {0, 0, 0, 0, 0};   // matcher tuning overrides (slam_bf_set_tuning), 0 = heuristic
-    void* bf_tbl_dev = nullptr;                     // chunk boundary table of the last search (device) ...
-    void* bf_tbl_host = nullptr;                    // ... and its pinned host copy
-    int bf_tbl_n = 0;
+    // chunk boundary tables of the recent searches: a ring of small slots + one big slot, device and pinned host
+    void* bf_tbl_dev = nullptr;
+    void* bf_tbl_host = nullptr;
+    int bf_tbl_n[SLAM_BF_TBL_RING + 1] = {};        // entries held by each slot
+    bool bf_tbl_busy[SLAM_BF_TBL_RING + 1] = {};    // an event is pending behind the slot's last launch
+    hipEvent_t bf_tbl_ev[SLAM_BF_TBL_RING] = {};
+    int bf_tbl_cur = 0;                             // slot of the most recent search
     void* scratch = nullptr;                        // 4 KiB device scratch (filter counters, reductions)
     void* io_dev = nullptr;                         // device arena of the host-buffer entry points (grow-only)
     uint64_t io_dev_bytes = 0;

@@ -17,13 +17,14 @@ handles, verdicts, timings) and a barrier.  This module provides them:
 """
 from __future__ import annotations
 
-import hashlib
 import os
+import pickle
+import socket
+import struct
 import subprocess
 import sys
 import threading
 import time
-from multiprocessing.connection import Client, Listener
 from typing import List, Optional, Sequence, Tuple
 
 
@@ -35,30 +36,61 @@ def _address(name: str) -> str:
     return "\0slamhip-" + name          # abstract namespace: no file to clean up, private to this network namespace
 
 
+def _send(sock: socket.socket, obj) -> None:
+    blob = pickle.dumps(obj, protocol=pickle.HIGHEST_PROTOCOL)      # our own objects between our own processes
+    sock.sendall(struct.pack("<Q", len(blob)) + blob)
+
+
+def _recv(sock: socket.socket, timeout: float):
+    """One framed object, or EOFError if the peer closed, or socket.timeout."""
+    sock.settimeout(timeout)
+    buf = bytearray()
+    need = 8
+    header = True
+    while True:
+        while len(buf) < need:
+            chunk = sock.recv(min(1 << 20, need - len(buf)))
+            if not chunk:
+                raise EOFError("peer closed the rendezvous connection")
+            buf += chunk
+        if header:
+            need, header = struct.unpack("<Q", bytes(buf))[0], False
+            buf = bytearray()
+            if need == 0:
+                return None
+        else:
+            return pickle.loads(bytes(buf))
+
+
 class _Server(threading.Thread):
     """Rank 0's side: accept `world` connections, then serve rounds of all-gather until every rank has said goodbye."""
 
     def __init__(self, name: str, world: int, timeout: float):
         super().__init__(daemon=True)
         self.world, self.timeout = world, timeout
-        self.listener = Listener(_address(name), family="AF_UNIX", authkey=hashlib.sha256(name.encode()).digest())
+        self.sock = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+        self.sock.bind(_address(name))
+        self.sock.listen(world)
         self.error: Optional[str] = None
 
     def run(self) -> None:
         conns = {}
         try:
-            self.listener._listener._socket.settimeout(self.timeout)
+            self.sock.settimeout(self.timeout)
             while len(conns) < self.world:
-                c = self.listener.accept()
-                conns[c.recv()] = c
+                c, _ = self.sock.accept()
+                conns[_recv(c, self.timeout)] = c
             while conns:
                 items, gone = {}, []
                 deadline = time.monotonic() + self.timeout
                 for r, c in sorted(conns.items()):
-                    if not c.poll(max(0.0, deadline - time.monotonic())):
+                    try:
+                        kind, payload = _recv(c, max(0.01, deadline - time.monotonic()))
+                    except socket.timeout:
                         raise RendezvousError(f"rank {r} did not reach the collective within {self.timeout:.0f} s "
-                                              f"(arrived: {sorted(items)})")
-                    kind, payload = c.recv()
+                                              f"(arrived: {sorted(items)})") from None
+                    except EOFError:
+                        raise RendezvousError(f"rank {r} went away (arrived: {sorted(items)})") from None
                     if kind == "bye":
                         gone.append(r)
                     else:
@@ -68,18 +100,20 @@ class _Server(threading.Thread):
                 for r in gone:
                     conns.pop(r).close()
                 if items:
-                    out = [items[r] for r in sorted(items)]
+                    out = ("ok", [items[r] for r in sorted(items)])
                     for c in conns.values():
-                        c.send(("ok", out))
+                        _send(c, out)
         except Exception as exc:   # noqa: BLE001 - tell whoever is still listening, then stop serving
             self.error = f"{type(exc).__name__}: {exc}"
             for c in conns.values():
                 try:
-                    c.send(("error", self.error))
+                    _send(c, ("error", self.error))
                 except OSError:
                     pass
         finally:
-            self.listener.close()
+            for c in conns.values():
+                c.close()
+            self.sock.close()
 
 
 class Rendezvous:
@@ -88,35 +122,37 @@ class Rendezvous:
     def __init__(self, rank: int, world: int, name: str, timeout: float = 180.0):
         self.rank, self.world, self.timeout = rank, world, timeout
         self._server = None
+        self._conn: Optional[socket.socket] = None
         if world <= 1:
-            self._conn = None
             return
         if rank == 0:
             self._server = _Server(name, world, timeout)
             self._server.start()
-        key = hashlib.sha256(name.encode()).digest()
         deadline = time.monotonic() + timeout
         while True:
+            c = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
             try:
-                self._conn = Client(_address(name), family="AF_UNIX", authkey=key)
+                c.connect(_address(name))
+                self._conn = c
                 break
             except (ConnectionRefusedError, FileNotFoundError):
+                c.close()
                 if time.monotonic() > deadline:
                     raise RendezvousError(f"rank {rank}: no rendezvous server '{name}' after {timeout:.0f} s") from None
                 time.sleep(0.02)
-        self._conn.send(rank)
+        _send(self._conn, rank)
 
     def allgather(self, obj) -> list:
         """[obj of rank 0, obj of rank 1, ...] on every rank.  Every rank must make the same sequence of calls."""
         if self._conn is None:
             return [obj]
-        self._conn.send(("item", obj))
-        if not self._conn.poll(self.timeout + 5.0):
-            raise RendezvousError(f"rank {self.rank}: no answer from the rendezvous server within {self.timeout:.0f} s")
         try:
-            kind, payload = self._conn.recv()
-        except EOFError:
-            raise RendezvousError(f"rank {self.rank}: the rendezvous server went away") from None
+            _send(self._conn, ("item", obj))
+            kind, payload = _recv(self._conn, self.timeout + 5.0)
+        except socket.timeout:
+            raise RendezvousError(f"rank {self.rank}: no answer from the rendezvous server within {self.timeout:.0f} s") from None
+        except (EOFError, OSError) as exc:
+            raise RendezvousError(f"rank {self.rank}: the rendezvous server went away ({exc})") from None
         if kind != "ok":
             raise RendezvousError(f"rank {self.rank}: {payload}")
         return payload
@@ -130,7 +166,7 @@ class Rendezvous:
     def close(self) -> None:
         if self._conn is not None:
             try:
-                self._conn.send(("bye", None))
+                _send(self._conn, ("bye", None))
             except OSError:
                 pass
             self._conn.close()

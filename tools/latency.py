@@ -18,6 +18,24 @@ for n in (200, 2000, 20000):
         for _ in range(50):
             f()
         print(f"n={n:6d} {name:28s} {(time.perf_counter() - t0) / 50 * 1e3:8.3f} ms per call")
+# the tracking loop as it really is: a different number of features on every frame (ORB finds what it finds), fresh copies of
+# both matrices per call (Frame.get_descriptors), the previous frame's rows recognised by the matcher's frame cache
+frames = [rng.integers(0, 256, (int(k), 32), dtype=np.uint8) for k in rng.integers(150, 201, 80)]
+for _ in range(2):
+    for a, b in zip(frames[:-1], frames[1:]):
+        bf.match(a.copy(), b.copy())
+t0 = time.perf_counter()
+for a, b in zip(frames[:-1], frames[1:]):
+    bf.match(a.copy(), b.copy())
+print(f"n=150..200 varying per frame, match(last.copy(), cur.copy()) -> MatchList  {(time.perf_counter() - t0) / 79 * 1e3:8.3f} ms per frame")
+cq, ct = frames[0], frames[1]
+for f, name in ((lambda: bf.cross_check_match(cq, ct), "cross_check_match (forward + reverse search)"),):
+    for _ in range(5):
+        f()
+    t0 = time.perf_counter()
+    for _ in range(50):
+        f()
+    print(f"n=   200 {name:40s} {(time.perf_counter() - t0) / 50 * 1e3:8.3f} ms per call")
 big_q = rng.integers(0, 256, (65536, 32), dtype=np.uint8); big_t = rng.integers(0, 256, (65536, 32), dtype=np.uint8)
 for _ in range(3):
     bf.knn_match_arrays(big_q, big_t, 2)
