@@ -219,7 +219,8 @@ template <int R>
 __global__ __launch_bounds__(256) void bf_top2_kernel(const uint4* __restrict__ q, int N,
                                                       const uint4* __restrict__ t, const int* __restrict__ tbl,
                                                       int lead, bf_state st, int train_base,
-                                                      int2* __restrict__ out_idx, int2* __restrict__ out_dist) {
+                                                      int2* __restrict__ out_idx, int2* __restrict__ out_dist,
+                                                      uint4* __restrict__ keep) {
     __shared__ uint4 tile[2][SLAM_TILE_ROWS * 2 + 4];
     __shared__ u32 s_last;
     u32* __restrict__ bound = st.bound;
@@ -234,6 +235,12 @@ __global__ __launch_bounds__(256) void bf_top2_kernel(const uint4* __restrict__ 
         int qi = qbase + r * 64;
         qi = qi < N ? qi : N - 1;  // clamp: tail lanes compute a duplicate and never store
         const uint4 a = q[2 * (size_t)qi], b = q[2 * (size_t)qi + 1];
+        if (keep && blockIdx.y == 0 && qbase + r * 64 < N) {
+            // the caller wants the query rows left in device memory (they are the next frame's train side,
+            // frontend.py:181-187): the first chunk's blocks have them in registers anyway
+            keep[2 * (size_t)qi] = a;
+            keep[2 * (size_t)qi + 1] = b;
+        }
         qr[r][0] = a.x; qr[r][1] = a.y; qr[r][2] = a.z; qr[r][3] = a.w;
         qr[r][4] = b.x; qr[r][5] = b.y; qr[r][6] = b.z; qr[r][7] = b.w;
     }
@@ -661,7 +668,7 @@ extern "C" int slam_bf_reset_state(slam_ctx* ctx) {
 
 // one pass over at most 2^23 train rows
 static int bf_pass(slam_ctx* ctx, const void* d_query, int64_t N, const void* d_train, int64_t M,
-                   int64_t train_base, int32_t* d_idx, int32_t* d_dist) {
+                   int64_t train_base, int32_t* d_idx, int32_t* d_dist, void* d_keep) {
     std::vector<int> tbl;
     const bf_plan p = make_plan(ctx, N, M, &tbl);
     bf_state st;
@@ -677,10 +684,10 @@ static int bf_pass(slam_ctx* ctx, const void* d_query, int64_t N, const void* d_
     SLAM_HIP(hipGetLastError());
     if (int rc = slam_prof_begin(ctx)) return rc;
     switch (p.R) {
-        case 8: bf_top2_kernel<8><<<grid, block, 0, ctx->stream>>>(q, (int)N, t, d_tbl, p.lead, st, tb, oi, od); break;
-        case 4: bf_top2_kernel<4><<<grid, block, 0, ctx->stream>>>(q, (int)N, t, d_tbl, p.lead, st, tb, oi, od); break;
-        case 2: bf_top2_kernel<2><<<grid, block, 0, ctx->stream>>>(q, (int)N, t, d_tbl, p.lead, st, tb, oi, od); break;
-        default: bf_top2_kernel<1><<<grid, block, 0, ctx->stream>>>(q, (int)N, t, d_tbl, p.lead, st, tb, oi, od); break;
+        case 8: bf_top2_kernel<8><<<grid, block, 0, ctx->stream>>>(q, (int)N, t, d_tbl, p.lead, st, tb, oi, od, (uint4*)d_keep); break;
+        case 4: bf_top2_kernel<4><<<grid, block, 0, ctx->stream>>>(q, (int)N, t, d_tbl, p.lead, st, tb, oi, od, (uint4*)d_keep); break;
+        case 2: bf_top2_kernel<2><<<grid, block, 0, ctx->stream>>>(q, (int)N, t, d_tbl, p.lead, st, tb, oi, od, (uint4*)d_keep); break;
+        default: bf_top2_kernel<1><<<grid, block, 0, ctx->stream>>>(q, (int)N, t, d_tbl, p.lead, st, tb, oi, od, (uint4*)d_keep); break;
     }
     if (int rc = slam_prof_end(ctx)) return rc;
     const hipError_t e = hipGetLastError();
@@ -693,6 +700,12 @@ static int bf_pass(slam_ctx* ctx, const void* d_query, int64_t N, const void* d_
 
 extern "C" int slam_bf_knn2_u256(slam_ctx* ctx, const void* d_query, int64_t N, const void* d_train,
                                  int64_t M, int64_t train_base, int32_t* d_idx, int32_t* d_dist) {
+    return slam_bf_knn2_keep(ctx, d_query, N, d_train, M, train_base, d_idx, d_dist, nullptr);
+}
+
+// slam_bf_knn2_u256 that also leaves a copy of the query rows at d_keep (device memory, 32*N bytes) when M > 0
+int slam_bf_knn2_keep(slam_ctx* ctx, const void* d_query, int64_t N, const void* d_train, int64_t M,
+                      int64_t train_base, int32_t* d_idx, int32_t* d_dist, void* d_keep) {
     SLAM_REQUIRE(ctx, "slam_bf_knn2_u256: null ctx");
     SLAM_REQUIRE(N >= 0 && M >= 0, "negative size (N=%lld, M=%lld)", (long long)N, (long long)M);
     SLAM_REQUIRE(N <= (1ll << 30), "N=%lld exceeds 2^30 query rows per call", (long long)N);
@@ -711,7 +724,8 @@ extern "C" int slam_bf_knn2_u256(slam_ctx* ctx, const void* d_query, int64_t N, 
     SLAM_REQUIRE(d_train, "slam_bf_knn2_u256: null train pointer");
     const int64_t PASS = SLAM_MAX_TRAIN_PER_PASS;
     const int64_t passes = (M + PASS - 1) / PASS;
-    if (passes == 1) return bf_pass(ctx, d_query, N, d_train, M, train_base, d_idx, d_dist);
+    SLAM_REQUIRE(((uintptr_t)d_keep & 15) == 0, "d_keep must be 16-byte aligned");
+    if (passes == 1) return bf_pass(ctx, d_query, N, d_train, M, train_base, d_idx, d_dist, d_keep);
     // train set larger than one key range: run passes into per-pass tables, then merge them
     const uint64_t tb = (uint64_t)passes * N * 2 * sizeof(int32_t);
     void* ws = nullptr;
@@ -721,7 +735,7 @@ extern "C" int slam_bf_knn2_u256(slam_ctx* ctx, const void* d_query, int64_t N, 
     for (int64_t p = 0; p < passes; p++) {
         const int64_t m0 = p * PASS, m = (M - m0) < PASS ? (M - m0) : PASS;
         if (int rc = bf_pass(ctx, d_query, N, (const char*)d_train + m0 * SLAM_DESC_BYTES, m, train_base + m0,
-                             idx_parts + p * N * 2, dist_parts + p * N * 2))
+                             idx_parts + p * N * 2, dist_parts + p * N * 2, p == 0 ? d_keep : nullptr))
             return rc;
     }
     return slam_bf_merge_top2(ctx, idx_parts, dist_parts, passes, N, d_idx, d_dist);

@@ -94,10 +94,15 @@ extern "C" int slam_bf_match_host(slam_ctx* ctx, const uint8_t* h_query, int64_t
     const bool zc = zero_copy(N, M);
     uint8_t* io = zc ? hb : db;
     const void* dq = io;
-    if (d_query_keep) {
+    void* keep_in_kernel = nullptr;
+    if (d_query_keep && zc) {
+        // frame-sized: the search reads the query rows from the pinned block and its first chunk's blocks, which hold
+        // them in registers, leave the device copy the caller asked for (no copy command, no DMA latency before the launch)
+        keep_in_kernel = d_query_keep;
+    } else if (d_query_keep) {
         // the caller keeps this frame's rows on the device as the next call's train side
         SLAM_HIP(hipMemcpyAsync(d_query_keep, hb, qbytes, hipMemcpyHostToDevice, ctx->stream));
-        if (tbytes && !zc) SLAM_HIP(hipMemcpyAsync(db + off_t, hb + off_t, tbytes, hipMemcpyHostToDevice, ctx->stream));
+        if (tbytes) SLAM_HIP(hipMemcpyAsync(db + off_t, hb + off_t, tbytes, hipMemcpyHostToDevice, ctx->stream));
         dq = d_query_keep;
     } else if (!zc) {
         SLAM_HIP(hipMemcpyAsync(db, hb, off_t + tbytes, hipMemcpyHostToDevice, ctx->stream));
@@ -112,7 +117,7 @@ extern "C" int slam_bf_match_host(slam_ctx* ctx, const uint8_t* h_query, int64_t
         int32_t* rev_dist = (int32_t*)(db + off_r + (uint64_t)M * 8);
         int32_t* o_idx = (int32_t*)(io + off_o);
         int32_t* o_dist = (int32_t*)(io + off_o + (uint64_t)N * 4);
-        if (int rc = slam_bf_knn2_u256(ctx, dq, N, dt, M, 0, fwd_idx, fwd_dist)) return rc;
+        if (int rc = slam_bf_knn2_keep(ctx, dq, N, dt, M, 0, fwd_idx, fwd_dist, keep_in_kernel)) return rc;
         if (int rc = slam_bf_knn2_u256(ctx, dt, M, dq, N, 0, rev_idx, rev_dist)) return rc;
         if (int rc = slam_cross_launch(ctx, fwd_idx, fwd_dist, N, rev_idx, M, o_idx, o_dist)) return rc;
         if (!zc) SLAM_HIP(hipMemcpyAsync(hb + off_o, db + off_o, (uint64_t)N * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -132,7 +137,7 @@ extern "C" int slam_bf_match_host(slam_ctx* ctx, const uint8_t* h_query, int64_t
     }
     int32_t* d_idx = (int32_t*)(io + off_i);
     int32_t* d_dist = (int32_t*)(io + off_d);
-    if (int rc = slam_bf_knn2_u256(ctx, dq, N, dt, M, 0, d_idx, d_dist)) return rc;
+    if (int rc = slam_bf_knn2_keep(ctx, dq, N, dt, M, 0, d_idx, d_dist, keep_in_kernel)) return rc;
     if (int rc = slam_filter_launch(ctx, d_idx, d_dist, N, mode, param, io + off_k)) return rc;
     if (!zc) SLAM_HIP(hipMemcpyAsync(hb + off_i, db + off_i, (uint64_t)N * 17, hipMemcpyDeviceToHost, ctx->stream));
     SLAM_HIP(hipStreamSynchronize(ctx->stream));

@@ -70,6 +70,10 @@ int slam_set_error(int code, const char* fmt, ...);
 int slam_workspace(slam_ctx* ctx, uint64_t bytes, void** out);
 // device arena + pinned staging of at least these sizes for one host-buffer call (stream-synchronising when they grow)
 int slam_io_arena(slam_ctx* ctx, uint64_t dev_bytes, uint64_t host_bytes, void** dev, void** host);
+// slam_bf_knn2_u256 that also leaves a copy of the query rows at d_keep (32*N bytes of device memory; M must be > 0
+// for the copy to happen: with no train rows no kernel reads the queries)
+int slam_bf_knn2_keep(slam_ctx* ctx, const void* d_query, int64_t N, const void* d_train, int64_t M, int64_t train_base,
+                      int32_t* d_idx, int32_t* d_dist, void* d_keep);
 // the filter kernels of slam_bf_match_filter without the read-back (asynchronous on the ctx stream)
 int slam_filter_launch(slam_ctx* ctx, const int32_t* d_idx, const int32_t* d_dist, int64_t N, int mode, double param,
                        uint8_t* d_keep);
