@@ -89,7 +89,7 @@ extern "C" int slam_bf_match_host(slam_ctx* ctx, const uint8_t* h_query, int64_t
     memcpy(hb, h_query, qbytes);
     if (tbytes) memcpy(hb + off_t, h_train, tbytes);
     ctx->io_h2d_bytes += qbytes + tbytes;                      // a train side passed as d_train crosses nothing
-    ctx->io_d2h_bytes += mode == 3 ? (uint64_t)N * 8 : (uint64_t)N * 17;
+    ctx->io_d2h_bytes += mode == 3 ? (uint64_t)N * 8 : (uint64_t)N * (mode ? 17 : 16);
     // frame-sized calls skip the copies: the kernels read the pinned block and write the result into it directly
     const bool zc = zero_copy(N, M);
     uint8_t* io = zc ? hb : db;
@@ -138,16 +138,20 @@ extern "C" int slam_bf_match_host(slam_ctx* ctx, const uint8_t* h_query, int64_t
     int32_t* d_idx = (int32_t*)(io + off_i);
     int32_t* d_dist = (int32_t*)(io + off_d);
     if (int rc = slam_bf_knn2_keep(ctx, dq, N, dt, M, 0, d_idx, d_dist, keep_in_kernel)) return rc;
-    if (int rc = slam_filter_launch(ctx, d_idx, d_dist, N, mode, param, io + off_k)) return rc;
-    if (!zc) SLAM_HIP(hipMemcpyAsync(hb + off_i, db + off_i, (uint64_t)N * 17, hipMemcpyDeviceToHost, ctx->stream));
+    // mode 0 (the reference's own call, dist_threshold=None, frontend.py:187) keeps every query that has a neighbour:
+    // that needs no reduction over the queries, so no selection kernel is launched for it (one launch less per frame)
+    const bool select = mode != 0;
+    if (select)
+        if (int rc = slam_filter_launch(ctx, d_idx, d_dist, N, mode, param, io + off_k)) return rc;
+    if (!zc) SLAM_HIP(hipMemcpyAsync(hb + off_i, db + off_i, (uint64_t)N * (select ? 17 : 16), hipMemcpyDeviceToHost, ctx->stream));
     SLAM_HIP(hipStreamSynchronize(ctx->stream));
-    // compact the kept rows (the selection itself was made on the device)
+    // compact the kept rows (for modes 1 and 2 the selection itself was made on the device)
     const int32_t* ri = (const int32_t*)(hb + off_i);
     const int32_t* rd = (const int32_t*)(hb + off_d);
     const uint8_t* rk = hb + off_k;
     int64_t c = 0;
     for (int64_t n = 0; n < N; n++) {
-        if (!rk[n]) continue;
+        if (select ? !rk[n] : ri[2 * n] < 0) continue;
         h_query_idx[c] = (int32_t)n;
         h_train_idx[c] = ri[2 * n];
         h_distance[c] = (float)rd[2 * n];   // cv2 reports CV_32S distances converted to float32
