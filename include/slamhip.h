@@ -203,6 +203,17 @@ SLAM_API int slam_pose_optimize_f64(slam_ctx* ctx, const double* d_pose_in, cons
                                     int rounds, int iterations, double chi2_threshold, double huber_delta,
                                     double* d_pose_out, uint8_t* d_inlier, double* d_chi2, int32_t* d_stats);
 
+/* The same for B independent frames in ONE launch (one workgroup per frame): frame b owns the edges
+ * [d_offsets[b], d_offsets[b+1]) of the concatenated d_points [O_total,3] / d_meas [O_total,2] (d_offsets int32 [B+1],
+ * ascending, d_offsets[0] = 0, d_offsets[B] = O_total; the caller guarantees that), d_pose_in / d_pose_out [B,12],
+ * d_inlier / d_chi2 [O_total], d_stats int32 [B,2].  Use: the keyframes of a window against the fixed map, or several
+ * relocalisation candidates; the reference refines one frame at a time (frontend.py:298-393). */
+SLAM_API int slam_pose_optimize_batch_f64(slam_ctx* ctx, int64_t B, const double* d_pose_in, const double* d_points,
+                                          const double* d_meas, const int32_t* d_offsets, int64_t O_total, double fx,
+                                          double fy, double cx, double cy, int rounds, int iterations,
+                                          double chi2_threshold, double huber_delta, double* d_pose_out,
+                                          uint8_t* d_inlier, double* d_chi2, int32_t* d_stats);
+
 /* ---- per-frame calls on caller-owned host buffers: one upload, one download, one synchronisation ---- */
 /* BruteForceFeatureMatcher.match (feature_matchers.py:36-44; cv2.BFMatcher.match + the min-distance filter) in
  * one call.  Query rows h_query [N,32]; train rows either h_train [M,32] (host) or d_train (device, e.g. the

@@ -78,6 +78,12 @@ class Backend:
         fn = _po.optimize_pose_only_device if on_device else _po.optimize_pose_only
         return fn(pose, points, meas, (fx, fy, cx, cy), rounds, iterations, ctx=self.ctx)
 
+    def optimize_poses(self, poses, points_list, meas_list, fx, fy, cx, cy, rounds: int = 4, iterations: int = 10):
+        """``optimize_pose`` for several independent frames in ONE kernel launch (one workgroup per frame): e.g. every
+        keyframe of the window against the fixed map, or relocalisation candidates.  Returns a list of
+        ``PoseOptResult``, identical to calling ``optimize_pose`` on each frame."""
+        return _po.optimize_poses_batch(poses, points_list, meas_list, (fx, fy, cx, cy), rounds, iterations, ctx=self.ctx)
+
     def optimize(self, poses, points, obs_pose_idx, obs_point_idx, meas, fx, fy, cx, cy, iterations: int = 10,
                  fixed_poses=(0,), huber_delta: float = 0.0, on_device: bool = True):
         """Bundle adjustment over a window of keyframes and their landmarks (``optimizer.optimize(10)`` in

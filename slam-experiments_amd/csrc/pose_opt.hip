@@ -273,12 +273,22 @@ __device__ __forceinline__ int po_run(po_shared& sh, const double* points, const
     return nactive;
 }
 
+// One workgroup per problem.  offsets == nullptr: a single problem of O edges.  Otherwise problem b = blockIdx.x owns the
+// edges [offsets[b], offsets[b+1]) of the concatenated point / pixel arrays, pose b of pose_in / pose_out and stats[2b..]:
+// independent frames (a window's keyframes against the fixed map, relocalisation candidates) refined in ONE launch.
 __global__ __launch_bounds__(PO_THREADS) void pose_opt_kernel(const double* __restrict__ pose_in,
                                                               const double* __restrict__ g_points,
-                                                              const double2* __restrict__ g_meas, int O, po_cam cam,
+                                                              const double2* __restrict__ g_meas, int O,
+                                                              const int* __restrict__ offsets, po_cam cam,
                                                               po_params prm, double* __restrict__ pose_out,
                                                               uint8_t* __restrict__ g_active,
                                                               double* __restrict__ g_chi2, int* __restrict__ stats) {
+    if (offsets) {
+        const int b = blockIdx.x, first = offsets[b];
+        O = offsets[b + 1] - first;
+        pose_in += 12 * b; pose_out += 12 * b; stats += 2 * b;
+        g_points += 3 * (size_t)first; g_meas += first; g_active += first; g_chi2 += first;
+    }
     // A frame has <= 200 edges (slam.py:23): the whole problem lives in LDS (24.5 KiB) and no evaluation touches
     // global memory.  Larger problems run the same code on the global arrays.
     __shared__ double s_points[PO_STAGE * 3];
@@ -318,8 +328,29 @@ extern "C" int slam_pose_optimize_f64(slam_ctx* ctx, const double* d_pose_in, co
     SLAM_HIP(hipSetDevice(ctx->device));
     const po_cam cam = {fx, fy, cx, cy};
     const po_params prm = {rounds, iterations, chi2_threshold, huber_delta};
-    pose_opt_kernel<<<1, PO_THREADS, 0, ctx->stream>>>(d_pose_in, d_points, (const double2*)d_meas, (int)O, cam, prm,
+    pose_opt_kernel<<<1, PO_THREADS, 0, ctx->stream>>>(d_pose_in, d_points, (const double2*)d_meas, (int)O, nullptr, cam, prm,
                                                        d_pose_out, d_inlier, d_chi2, d_stats);
+    SLAM_HIP(hipGetLastError());
+    return SLAM_OK;
+}
+
+extern "C" int slam_pose_optimize_batch_f64(slam_ctx* ctx, int64_t B, const double* d_pose_in, const double* d_points,
+                                            const double* d_meas, const int32_t* d_offsets, int64_t O_total, double fx,
+                                            double fy, double cx, double cy, int rounds, int iterations,
+                                            double chi2_threshold, double huber_delta, double* d_pose_out,
+                                            uint8_t* d_inlier, double* d_chi2, int32_t* d_stats) {
+    SLAM_REQUIRE(ctx, "slam_pose_optimize_batch_f64: null ctx");
+    SLAM_REQUIRE(B >= 0 && B <= (1 << 20) && O_total >= 0 && O_total <= (1 << 28), "bad sizes (B=%lld, O=%lld)", (long long)B, (long long)O_total);
+    SLAM_REQUIRE(rounds >= 0 && iterations >= 0 && rounds <= 64 && iterations <= 1000, "bad rounds / iterations");
+    if (B == 0) return SLAM_OK;
+    SLAM_REQUIRE(d_pose_in && d_pose_out && d_stats && d_offsets && (O_total == 0 || (d_points && d_meas && d_inlier && d_chi2)),
+                 "slam_pose_optimize_batch_f64: null device pointer");
+    SLAM_REQUIRE(((uintptr_t)d_meas & 15) == 0, "d_meas must be 16-byte aligned");
+    SLAM_HIP(hipSetDevice(ctx->device));
+    const po_cam cam = {fx, fy, cx, cy};
+    const po_params prm = {rounds, iterations, chi2_threshold, huber_delta};
+    pose_opt_kernel<<<(unsigned)B, PO_THREADS, 0, ctx->stream>>>(d_pose_in, d_points, (const double2*)d_meas, 0, d_offsets, cam, prm,
+                                                                 d_pose_out, d_inlier, d_chi2, d_stats);
     SLAM_HIP(hipGetLastError());
     return SLAM_OK;
 }

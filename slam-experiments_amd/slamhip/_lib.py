@@ -64,6 +64,9 @@ SIGNATURES = {
     "slam_pose_optimize_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double, c_double, c_double,
                                        c_double, c_int, c_int, c_double, c_double, c_void_p, c_void_p, c_void_p,
                                        c_void_p]),
+    "slam_pose_optimize_batch_f64": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double,
+                                             c_double, c_double, c_double, c_int, c_int, c_double, c_double, c_void_p,
+                                             c_void_p, c_void_p, c_void_p]),
     "slam_bf_match_host": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_double,
                                    c_void_p, c_void_p, c_void_p, c_void_p]),
     "slam_index_errors": (c_int, [c_void_p, POINTER(c_int64)]),

@@ -172,3 +172,57 @@ def optimize_pose_only_device(pose, points, meas, intrinsics, rounds: int = 4, i
                                               chi2.ctypes.data if O else None, stats.ctypes.data))
     T[:3, :4] = out12.reshape(3, 4)
     return PoseOptResult(pose=T, inliers=inl.astype(bool), chi2=chi2, n_inliers=int(stats[0]), iterations=int(stats[1]))
+
+
+def optimize_poses_batch(poses, points_list, meas_list, intrinsics, rounds: int = 4, iterations: int = 10,
+                         chi2_threshold: float = CHI2_THRESHOLD, huber_delta: float = HUBER_DELTA,
+                         ctx: Optional[Context] = None):
+    """``optimize_pose_only_device`` for several independent frames in ONE kernel launch (one workgroup per frame,
+    ``slam_pose_optimize_batch_f64``): ``poses`` [B,4,4] (or [B,3,4]), ``points_list[b]`` [O_b,3], ``meas_list[b]`` [O_b,2].
+    Returns a list of ``PoseOptResult``.  The reference refines one frame per call (``frontend.py:298-393``); this is
+    for the keyframes of a window against the fixed map, or relocalisation candidates."""
+    from ._lib import check
+
+    ctx = ctx or default_context()
+    P = np.asarray(poses, np.float64)
+    B = P.shape[0]
+    if len(points_list) != B or len(meas_list) != B:
+        raise ValueError("one point array and one pixel array per pose")
+    if B == 0:
+        return []
+    pin = np.ascontiguousarray(P.reshape(B, -1, 4)[:, :3, :4].reshape(B, 12))
+    pts = [np.ascontiguousarray(p, np.float64).reshape(-1, 3) for p in points_list]
+    mes = [np.ascontiguousarray(m, np.float64).reshape(-1, 2) for m in meas_list]
+    if any(p.shape[0] != m.shape[0] for p, m in zip(pts, mes)):
+        raise ValueError("one measurement per point in every frame")
+    off = np.zeros(B + 1, np.int32)
+    off[1:] = np.cumsum([p.shape[0] for p in pts])
+    O = int(off[-1])
+    fx, fy, cx, cy = (float(v) for v in intrinsics)
+    bufs = []
+    try:
+        d_pose = ctx.upload(pin); bufs.append(d_pose)
+        d_pts = ctx.upload(np.concatenate(pts) if O else np.zeros((1, 3))); bufs.append(d_pts)
+        d_mes = ctx.upload(np.concatenate(mes) if O else np.zeros((1, 2))); bufs.append(d_mes)
+        d_off = ctx.upload(off); bufs.append(d_off)
+        d_out = ctx.malloc(B * 96); bufs.append(d_out)
+        d_inl = ctx.malloc(max(O, 1)); bufs.append(d_inl)
+        d_chi = ctx.malloc(max(O, 1) * 8); bufs.append(d_chi)
+        d_st = ctx.malloc(B * 8); bufs.append(d_st)
+        check(ctx.lib.slam_pose_optimize_batch_f64(ctx.handle, B, d_pose.ptr, d_pts.ptr, d_mes.ptr, d_off.ptr, O, fx, fy, cx, cy,
+                                                   int(rounds), int(iterations), float(chi2_threshold), float(huber_delta),
+                                                   d_out.ptr, d_inl.ptr, d_chi.ptr, d_st.ptr))
+        out = d_out.download(np.float64, (B, 3, 4))
+        inl = d_inl.download(np.uint8, (max(O, 1),)).astype(bool)
+        chi = d_chi.download(np.float64, (max(O, 1),))
+        st = d_st.download(np.int32, (B, 2))
+    finally:
+        for b in bufs:
+            b.free()
+    res = []
+    for b in range(B):
+        T = np.eye(4)
+        T[:3, :4] = out[b]
+        a, e = int(off[b]), int(off[b + 1])
+        res.append(PoseOptResult(pose=T, inliers=inl[a:e].copy(), chi2=chi[a:e].copy(), n_inliers=int(st[b, 0]), iterations=int(st[b, 1])))
+    return res

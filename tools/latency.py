@@ -67,3 +67,11 @@ for on_device in (False, True):
     for _ in range(20):
         r = be.optimize_pose(T0, X, pix, 458.654, 457.296, 367.215, 248.375, on_device=on_device)
     print(f"optimize_pose 200 edges, {'one launch on device' if on_device else 'host-driven LM      '}: {(time.perf_counter() - t0) / 20 * 1e3:7.3f} ms per call, {r.iterations} accepted steps")
+# several frames refined in one launch (one workgroup per frame) against the same work one launch at a time
+ps = [se3_exp(rng.normal(0, 0.01, 6)) @ T for _ in range(16)]
+for _ in range(3):
+    be.optimize_poses(np.stack(ps), [X] * 16, [pix] * 16, 458.654, 457.296, 367.215, 248.375)
+t0 = time.perf_counter()
+for _ in range(10):
+    be.optimize_poses(np.stack(ps), [X] * 16, [pix] * 16, 458.654, 457.296, 367.215, 248.375)
+print(f"optimize_poses 16 frames x 200 edges, one launch: {(time.perf_counter() - t0) / 10 * 1e3:7.3f} ms per call ({(time.perf_counter() - t0) / 160 * 1e3:.3f} ms per frame)")
