@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256) void bf_top2_kernel(const uint4* __restrict__ 
         // a whole group's reads behind immediate offsets is 6 % slower than this rolling form.
         int j = 0;
         uint4 a0 = tp[0], c0 = tp[1];
-        constexpr int U = SLAM_GROUP_PAIRS / R;   // 16 rows at R = 1 (58 VGPRs, still 8 waves/SIMD)
+        constexpr int U = SLAM_GROUP_PAIRS / R;   // 16 rows at R = 1 (59 VGPRs, still 8 waves/SIMD)
         static_assert(U >= 2 && U % 2 == 0, "row pipeline handles rows in pairs");
         // A block starts with no threshold of its own, so in its first tile nearly every group takes the
         // update path; there the bound is re-read after 16, 32, 64 and 128 rows (what the sibling blocks
