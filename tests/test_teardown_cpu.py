@@ -90,3 +90,43 @@ def test_close_then_barrier_then_free(kind, monkeypatch):
     del log[:]
     sm2.free()
     assert "barrier" not in log and any(x.startswith("free:") for x in log)
+
+
+def test_step_sequence_of_the_sharded_matchers(monkeypatch):
+    """What one pass issues, in order, on the recording library: wait for the gather that last used the buffer, search
+    into this rank's slot, gather that buffer on the second stream; two buffers alternate between passes (the gather of
+    pass i overlaps the search of pass i+1).  The train-sharded matcher gathers both tables and merges them by
+    (distance, index) when the result is read."""
+    from slamhip import dist
+
+    log = []
+    ctx = _Ctx(log)
+    monkeypatch.setattr(dist, "DeviceDescriptors", lambda c, rows: type("D", (), {"buf": _Buf(log, 32 * max(len(rows), 1), "descriptors"), "free": lambda self: None})())
+    q, t = np.zeros((10, 32), np.uint8), np.zeros((20, 32), np.uint8)
+    sm = dist.ShardedMatcher(ctx, 1, 4, q, t, collective="rccl")
+    assert sm.n_local == 3 and sm.per == 3 and sm.slot_bytes == 48 and len(sm.gathered) == 2     # rows 3..5 of 10 on rank 1 of 4
+    del log[:]
+    for _ in range(3):
+        sm.step()
+    calls = [x for x in log if x.startswith("slam_")]
+    assert calls == ["slam_comm_wait_buffer", "slam_bf_knn2_u256", "slam_comm_allgather_overlapped"] * 3
+    assert sm.passes == 3 and sm.last == 0                                                       # buffers 0, 1, 0
+    # a rank whose shard is empty (more ranks than rows) still takes part in every gather
+    sm_empty = dist.ShardedMatcher(ctx, 3, 4, q[:2], t, collective="rccl")
+    assert sm_empty.n_local == 0
+    del log[:]
+    sm_empty.step()
+    assert [x for x in log if x.startswith("slam_")] == ["slam_comm_wait_buffer", "slam_comm_allgather_overlapped"]
+    # train-sharded: one search with global indices, two gathers (idx table, dist table), merge on read
+    ts = dist.TrainShardedMatcher(ctx, 2, 4, q, t[:5], 10, collective="rccl")
+    del log[:]
+    ts.step()
+    assert [x for x in log if x.startswith("slam_")] == ["slam_comm_wait_buffer"] * 2 + ["slam_bf_knn2_u256"] + ["slam_comm_allgather_overlapped"] * 2
+    del log[:]
+    ts.result()
+    assert "slam_bf_merge_top2" in log and log.index("sync") < log.index("slam_bf_merge_top2")
+    # a single rank issues no collective at all
+    one = dist.ShardedMatcher(ctx, 0, 1, q, t)
+    del log[:]
+    one.step()
+    assert [x for x in log if x.startswith("slam_")] == ["slam_bf_knn2_u256"]
