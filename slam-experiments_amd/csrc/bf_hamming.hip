@@ -88,19 +88,31 @@ __device__ __forceinline__ uint4 lds_read16(u32 addr, int byte_offset) {
 // acc[r] = 2^31 - th[r] + d  =>  d < th[r]  <=>  acc[r] < 2^31 (sign bit clear)
 //
 // R = 1 issues the row as ONE block: the eight v_xor first (each overwrites its train word, which is dead afterwards,
-// so no extra registers), then the eight accumulating v_bcnt.  On gfx950 a 2-cycle-class op that alternates with
-// 4-cycle-class ops is issued at the 4-cycle rate in a synthetic loop: the alternating order (what the compiler emits
-// from the C++ form) costs 4.45 cycles per instruction, as much as v_bcnt alone, where eight of a kind followed by eight
-// of the other cost 3.78 (tools/ubench/class_order.hip, profiles/r02_ubench_class_order.log).  In the kernel, where
-// eight waves with drifting phases share the SIMD, both orders run alike (1543 vs 1558 us): the sustained rates of the
-// two instructions themselves, 2.54 and 4.48 cycles, are what bounds it (8 x 2.54 + 8 x 4.48 = 56.2 cycles per row;
-// the kernel runs at 56.3-56.6).  The block form stays because it fixes the order against compiler changes.
+// so no extra registers), then the eight accumulating v_bcnt, with the wave's PRIORITY raised for the v_bcnt half.
+//
+// Why the priority (round 3, tools/ubench/cycles.hip, profiles/r03_ubench_cycles.log - all in measured shader cycles,
+// s_memtime against s_memrealtime, in-kernel clock 2.35-2.39 GHz): a gfx950 SIMD executes a wave64 VALU instruction
+// in 4 cycles and can run TWO at once when they come from different waves and at least one of them is a "simple" op
+// (v_xor/and/or/add/mov ...): a stream of v_xor from 8 waves costs 2.08 cycles per instruction, a stream of v_bcnt
+// 4.05 - but four waves of pure v_xor next to four waves of pure v_bcnt cost 2.17 per instruction TOGETHER when the
+// v_bcnt waves have the higher priority (2.65 with equal priorities, 3.6 when the v_xor waves have it).  v_bcnt can
+// only use one of the two issue slots; whoever is served first takes that slot, so a v_xor served first blocks the
+// v_bcnt of the next wave for 4 cycles while the second slot idles.  Arbitration is by priority, then age: with equal
+// priorities the oldest wave is served first whatever it holds, and every bare loop of this row measured 3.7-4.0 cycles
+// per instruction (59-64 per row; the round-2 kernel: 54.9, its waves drift apart at waits and branches).  With
+// s_setprio 2 in front of the v_bcnt half and s_setprio 0 in front of the v_xor half, a wave in its v_bcnt half is
+// served first and the v_xor of the other waves fill the second slot: the same bare loop runs at 2.24 cycles per
+// instruction (35.8 per row), and this kernel went from 1.514 to 1.24-1.26 ms at 64k x 64k (profiles/r03_ab_setprio.log).
+// The priority stays raised through the LDS reads and the filter that follow the row (placing s_setprio 0 right
+// behind the last v_bcnt measured 2 % slower at 64k x 64k) and is dropped when the scan ends.
 template <int R>
 __device__ __forceinline__ void row_acc(const u32 (&q)[R][8], uint4 a, uint4 b, const u32 (&init)[R],
                                         u32 (&acc)[R]) {
     if constexpr (R == 1) {
-        asm("v_xor_b32 %1, %9, %1\n\tv_xor_b32 %2, %10, %2\n\tv_xor_b32 %3, %11, %3\n\tv_xor_b32 %4, %12, %4\n\t"
+        asm volatile("s_setprio 0\n\t"
+            "v_xor_b32 %1, %9, %1\n\tv_xor_b32 %2, %10, %2\n\tv_xor_b32 %3, %11, %3\n\tv_xor_b32 %4, %12, %4\n\t"
             "v_xor_b32 %5, %13, %5\n\tv_xor_b32 %6, %14, %6\n\tv_xor_b32 %7, %15, %7\n\tv_xor_b32 %8, %16, %8\n\t"
+            "s_setprio 2\n\t"
             "v_bcnt_u32_b32 %0, %1, %17\n\tv_bcnt_u32_b32 %0, %2, %0\n\tv_bcnt_u32_b32 %0, %3, %0\n\t"
             "v_bcnt_u32_b32 %0, %4, %0\n\tv_bcnt_u32_b32 %0, %5, %0\n\tv_bcnt_u32_b32 %0, %6, %0\n\t"
             "v_bcnt_u32_b32 %0, %7, %0\n\tv_bcnt_u32_b32 %0, %8, %0"
@@ -331,6 +343,7 @@ __global__ __launch_bounds__(256) void bf_top2_kernel(const uint4* __restrict__ 
     }
 
     // ---- epilogue: merge, then the last arriver of this query block decodes ----------------------
+    __builtin_amdgcn_s_setprio(0);   // the scan raised it (row_acc); merges and tickets run at the default priority
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const int qi = qbase + r * 64;

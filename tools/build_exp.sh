@@ -5,6 +5,8 @@
 #   libslamhip_trace.so      every block stamps wall_clock64() at start / after the prologue / after the scan / at the end
 #   libslamhip_keepbound.so  the last arriver leaves the final 2nd-best distance in bound[] instead of restoring it
 #   libslamhip_count.so      counts, per launch, the 16-row groups and the single rows that take the update path
+#   libslamhip_cycles.so     wave 0 of every block stamps s_memtime (shader cycles) AND s_memrealtime (100 MHz) at block
+#                            start / after the prologue / after the scan / at the end, into a buffer of its own
 set -euo pipefail
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 SRC="$ROOT/slam-experiments_amd/csrc"
@@ -15,7 +17,7 @@ make -C "$SRC" -j8 all >/dev/null
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$ROOT/include -I/opt/rocm/include -I$SRC -fvisibility=hidden -DSLAM_BUILD"
 OBJS=$(ls "$ROOT"/slam-experiments_amd/lib/obj/*.o | grep -v bf_hamming)
 
-python3 - "$SRC/bf_hamming.hip" "$TMP/bf_trace.hip" "$TMP/bf_keep.hip" "$TMP/bf_count.hip" <<'EOF'
+python3 - "$SRC/bf_hamming.hip" "$TMP/bf_trace.hip" "$TMP/bf_keep.hip" "$TMP/bf_count.hip" "$TMP/bf_cycles.hip" <<'EOF'
 import sys
 src = open(sys.argv[1]).read()
 T = '    if (tid == 0 && g_trace) { g_trace[4*(blockIdx.y*gridDim.x+blockIdx.x)+%d] = wall_clock64(); }\n'
@@ -41,12 +43,25 @@ c = c.replace('typedef uint32_t u32;', 'typedef uint32_t u32;\n__device__ unsign
               'extern "C" __attribute__((visibility("default"))) int slam_exp_set_fire(void* p) '
               '{ return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_fire), &p, sizeof(p)); }', 1)
 open(sys.argv[4], 'w').write(c)
+# cycle stamps: one asm statement per stamp (s_memtime + s_memrealtime + the wait), wave 0 lane 0 stores both
+C = ('    if (g_cyc) { unsigned long long c_, r_; asm volatile("s_memtime %%0\\n\\ts_memrealtime %%1\\n\\ts_waitcnt lgkmcnt(0)" : "=s"(c_), "=s"(r_) :: "memory");\n'
+     '        if (tid == 0) { g_cyc[8*(blockIdx.y*gridDim.x+blockIdx.x)+%d] = c_; g_cyc[8*(blockIdx.y*gridDim.x+blockIdx.x)+%d] = r_; } }\n')
+y = src.replace('    const bool leader = (int)blockIdx.y < lead;\n', C % (0, 1) + '    const bool leader = (int)blockIdx.y < lead;\n', 1)
+y = y.replace('    int buf = 0;\n', C % (2, 3) + '    int buf = 0;\n', 1)
+y = y.replace('    // ---- epilogue: merge,', C % (4, 5) + '    // ---- epilogue: merge,', 1)
+y = y.replace('    if (!s_last) return;\n', C % (6, 7) + '    if (!s_last) return;\n', 1)
+y = y.replace('typedef uint32_t u32;', 'typedef uint32_t u32;\n__device__ unsigned long long* g_cyc = nullptr;\n'
+              'extern "C" __attribute__((visibility("default"))) int slam_exp_set_cycles(void* p) '
+              '{ return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_cyc), &p, sizeof(p)); }', 1)
+assert y.count('g_cyc[') == 8, "cycle hooks did not apply: the kernel source changed"
+open(sys.argv[5], 'w').write(y)
 EOF
-for v in trace keep count; do
+for v in trace keep count cycles; do
     /opt/rocm/bin/hipcc $FLAGS -c "$TMP/bf_$v.hip" -o "$TMP/bf_$v.o"
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libslamhip_trace.so" "$TMP/bf_trace.o" $OBJS -ldl
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libslamhip_keepbound.so" "$TMP/bf_keep.o" $OBJS -ldl
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libslamhip_count.so" "$TMP/bf_count.o" $OBJS -ldl
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libslamhip_cycles.so" "$TMP/bf_cycles.o" $OBJS -ldl
 rm -rf "$TMP"
 ls -la "$OUT"
