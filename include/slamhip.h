@@ -205,7 +205,8 @@ SLAM_API int slam_pose_optimize_f64(slam_ctx* ctx, const double* d_pose_in, cons
 
 /* The same for B independent frames in ONE launch (one workgroup per frame): frame b owns the edges
  * [d_offsets[b], d_offsets[b+1]) of the concatenated d_points [O_total,3] / d_meas [O_total,2] (d_offsets int32 [B+1],
- * ascending, d_offsets[0] = 0, d_offsets[B] = O_total; the caller guarantees that), d_pose_in / d_pose_out [B,12],
+ * ascending, d_offsets[0] = 0, d_offsets[B] = O_total; a table that is not ascending or leaves [0, O_total] never
+ * causes an access outside the arrays: the frame shrinks to the part inside and slam_index_errors counts it), d_pose_in / d_pose_out [B,12],
  * d_inlier / d_chi2 [O_total], d_stats int32 [B,2].  Use: the keyframes of a window against the fixed map, or several
  * relocalisation candidates; the reference refines one frame at a time (frontend.py:298-393). */
 SLAM_API int slam_pose_optimize_batch_f64(slam_ctx* ctx, int64_t B, const double* d_pose_in, const double* d_points,

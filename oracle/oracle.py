@@ -38,7 +38,7 @@ IMGIDX_SHIFT = 18  # OpenCV matchers.cpp: index = imgIdx << 18 | trainIdx
 
 def build(force: bool = False) -> str:
     """Compile liboracle.so with gcc (used by __graft_entry__.build())."""
-    srcs = [os.path.join(_HERE, f) for f in ("bf_hamming_oracle.c", "reproj_oracle.c")]
+    srcs = [os.path.join(_HERE, f) for f in ("bf_hamming_oracle.c", "reproj_oracle.c", "pose_lm_oracle.c")]
     stale = force or not os.path.exists(_LIB_PATH) or any(
         os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs
     )
@@ -71,6 +71,8 @@ def _load():
     lib.oracle_reproj_rj_f64.restype = i32
     lib.oracle_pose_normal_eq_f64.argtypes = [vp, vp, vp, vp, i64, dbl, dbl, dbl, dbl, dbl, vp, vp, vp]
     lib.oracle_pose_normal_eq_f64.restype = i32
+    lib.oracle_pose_lm_f64.argtypes = [vp, vp, vp, i64, dbl, dbl, dbl, dbl, i32, i32, dbl, dbl, vp, vp, vp, vp, vp]
+    lib.oracle_pose_lm_f64.restype = i32
     _lib = lib
     return lib
 
@@ -369,6 +371,27 @@ def pose_lm_np(pose, points, meas, fx, fy, cx, cy, rounds: int = 4, iterations: 
         if rnd == 2:
             delta = 0.0
     return T, active, chi2, accepted
+
+
+def pose_lm_c(pose, points, meas, fx, fy, cx, cy, rounds: int = 4, iterations: int = 10,
+              chi2_threshold: float = 5.991 ** 2, huber_delta: float = 1.0):
+    """The same loop in plain C on one host core (oracle/pose_lm_oracle.c: Gaussian elimination instead of numpy's
+    solver, a scaling-and-squaring series instead of scipy's expm): the CPU baseline of the pose refinement, and a
+    second oracle-side statement that the CPU suite holds against ``pose_lm_np``.
+    Returns (T 3x4 as 12 doubles, inliers bool [O], chi2 [O], accepted steps)."""
+    P = np.ascontiguousarray(np.asarray(pose, np.float64).reshape(-1)[:12])
+    points = np.ascontiguousarray(points, np.float64).reshape(-1, 3)
+    meas = np.ascontiguousarray(meas, np.float64).reshape(-1, 2)
+    O = points.shape[0]
+    out = np.empty(12)
+    inl = np.empty(max(O, 1), np.uint8)
+    chi2 = np.empty(max(O, 1))
+    stats = np.zeros(2, np.int32)
+    work = np.empty(2 * max(O, 1))
+    rc = _load().oracle_pose_lm_f64(_p(P), _p(points), _p(meas), O, fx, fy, cx, cy, int(rounds), int(iterations),
+                                    float(chi2_threshold), float(huber_delta), _p(out), _p(inl), _p(chi2), _p(stats), _p(work))
+    assert rc == 0
+    return out, inl[:O].astype(bool), chi2[:O], int(stats[1])
 
 
 def ba_schur_np(poses12, points, obs_pose, obs_point, meas, fx, fy, cx, cy, huber_delta: float, lam: float):

@@ -622,16 +622,28 @@ static int bf_table_get(slam_ctx* ctx, const std::vector<int>& tbl, const int** 
     std::lock_guard<std::mutex> g(ctx->mu);
     const size_t n = tbl.size();
     SLAM_REQUIRE(n <= SLAM_BF_TBL_MAX, "train set needs %zu chunks, more than one launch can index", n - 1);
-    if (!ctx->bf_tbl_dev) {
+    if (!ctx->bf_tbl_ready) {
+        // all or nothing: the table storage counts as initialised only when the device block, the pinned block and every
+        // event exist; a partial failure frees what it got, so the next call starts over instead of meeting a null pointer
         const size_t ints = (size_t)SLAM_BF_TBL_RING * SLAM_BF_TBL_SLOT + SLAM_BF_TBL_MAX;
-        SLAM_HIP(hipMalloc(&ctx->bf_tbl_dev, ints * sizeof(int)));
-        SLAM_HIP(hipHostMalloc(&ctx->bf_tbl_host, ints * sizeof(int), hipHostMallocDefault));
+        hipError_t e = hipMalloc(&ctx->bf_tbl_dev, ints * sizeof(int));
+        if (e == hipSuccess) e = hipHostMalloc(&ctx->bf_tbl_host, ints * sizeof(int), hipHostMallocDefault);
+        int made = 0;
+        for (; e == hipSuccess && made < SLAM_BF_TBL_RING; made++)
+            e = hipEventCreateWithFlags(&ctx->bf_tbl_ev[made], hipEventDisableTiming);
+        if (e != hipSuccess) {
+            for (int i = 0; i < made - 1; i++) (void)hipEventDestroy(ctx->bf_tbl_ev[i]);
+            if (ctx->bf_tbl_host) (void)hipHostFree(ctx->bf_tbl_host);
+            if (ctx->bf_tbl_dev) (void)hipFree(ctx->bf_tbl_dev);
+            ctx->bf_tbl_host = ctx->bf_tbl_dev = nullptr;
+            return slam_set_error(SLAM_ERR_HIP, "chunk table storage: %s", hipGetErrorString(e));
+        }
         for (int i = 0; i <= SLAM_BF_TBL_RING; i++) {
             ctx->bf_tbl_n[i] = 0;
             ctx->bf_tbl_busy[i] = false;
-            if (i < SLAM_BF_TBL_RING) SLAM_HIP(hipEventCreateWithFlags(&ctx->bf_tbl_ev[i], hipEventDisableTiming));
         }
         ctx->bf_tbl_cur = 0;
+        ctx->bf_tbl_ready = true;
     }
     int* host = (int*)ctx->bf_tbl_host;
     int* dev = (int*)ctx->bf_tbl_dev;
@@ -656,13 +668,16 @@ static int bf_table_get(slam_ctx* ctx, const std::vector<int>& tbl, const int** 
             }
             ctx->bf_tbl_cur = slot;
         }
+        // the slot is recorded as holding this table only once the copy (and its event) are queued: after a failure it
+        // holds nothing, so a later search of the same shape uploads again instead of launching on stale bounds
+        ctx->bf_tbl_n[slot] = 0;
         memcpy(host + off, tbl.data(), n * sizeof(int));
-        ctx->bf_tbl_n[slot] = (int)n;
         SLAM_HIP(hipMemcpyAsync(dev + off, host + off, n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
         if (!big) {
             SLAM_HIP(hipEventRecord(ctx->bf_tbl_ev[slot], ctx->stream));
             ctx->bf_tbl_busy[slot] = true;
         }
+        ctx->bf_tbl_n[slot] = (int)n;
     }
     *d_tbl = dev + off;
     return SLAM_OK;

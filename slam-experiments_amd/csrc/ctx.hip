@@ -18,7 +18,7 @@ int slam_set_error(int code, const char* fmt, ...) {
 }
 
 extern "C" const char* slam_last_error(void) { return g_err; }
-extern "C" const char* slam_version(void) { return "slamhip 0.1 (gfx950)"; }
+extern "C" const char* slam_version(void) { return "slamhip 0.3 (gfx950)"; }
 
 extern "C" int slam_device_count(int* count) {
     SLAM_REQUIRE(count, "slam_device_count: null out pointer");
@@ -53,7 +53,9 @@ extern "C" int slam_ctx_create(int device, slam_ctx** out) {
     if (e == hipSuccess) e = hipEventCreate(&c->ev_start);
     if (e == hipSuccess) e = hipEventCreate(&c->ev_stop);
     if (e == hipSuccess) e = hipMalloc(&c->scratch, 4096);
-    if (e == hipSuccess) e = hipMemset(c->scratch, 0, 4096);
+    // on the context's own (non-blocking) stream: a null-stream memset is not ordered against the first kernels there
+    if (e == hipSuccess) e = hipMemsetAsync(c->scratch, 0, 4096, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) {
         delete c;
         return slam_set_error(SLAM_ERR_HIP, "context setup failed: %s", hipGetErrorString(e));
@@ -74,11 +76,11 @@ extern "C" int slam_ctx_destroy(slam_ctx* ctx) {
     if (ctx->io_dev) (void)hipFree(ctx->io_dev);
     if (ctx->io_host) (void)hipHostFree(ctx->io_host);
     if (ctx->bf_state_mem) (void)hipFree(ctx->bf_state_mem);
-    if (ctx->bf_tbl_dev) {
+    if (ctx->bf_tbl_ready) {
         (void)hipFree(ctx->bf_tbl_dev);
+        (void)hipHostFree(ctx->bf_tbl_host);
         for (int i = 0; i < SLAM_BF_TBL_RING; i++) (void)hipEventDestroy(ctx->bf_tbl_ev[i]);
     }
-    if (ctx->bf_tbl_host) (void)hipHostFree(ctx->bf_tbl_host);
     if (ctx->prof_ev) {
         for (int i = 0; i < 2 * slam_ctx::PROF_MAX; i++) (void)hipEventDestroy(ctx->prof_ev[i]);
         delete[] ctx->prof_ev;

@@ -26,6 +26,7 @@ struct slam_ctx {
     // chunk boundary tables of the recent searches: a ring of small slots + one big slot, device and pinned host
     void* bf_tbl_dev = nullptr;
     void* bf_tbl_host = nullptr;
+    bool bf_tbl_ready = false;                      // device block, pinned block and all ring events exist
     int bf_tbl_n[SLAM_BF_TBL_RING + 1] = {};        // entries held by each slot
     bool bf_tbl_busy[SLAM_BF_TBL_RING + 1] = {};    // an event is pending behind the slot's last launch
     hipEvent_t bf_tbl_ev[SLAM_BF_TBL_RING] = {};

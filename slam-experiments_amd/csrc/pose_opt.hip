@@ -11,6 +11,17 @@
 // so results are run-to-run identical), lane 0 solves the damped 6x6 system by
 // LDL^T and drives g2o's published LM schedule.
 //
+// Measured and dropped (round 3, tools/pose_lm_probe.py, profiles/r03_pose_lm.log): the whole refinement on ONE wave
+// for frames of <= 256 edges (up to 4 edges per lane in registers, no barrier at all, every lane running the solve
+// redundantly on wave-uniform values): 338 / 394 / 409 us at 50 / 200 / 256 edges against 317 / 339 / 284 us for this
+// 256-thread form - a lone wave exposes the latency of every dependent f64 instruction, which costs more than the ten
+// barriers per trial it saves.  Where the time goes: the schedule makes ~70 trials (24 accepted, and every round ends
+// with ten rejected ones: g2o gives up after maxTrialsAfterFailure), a trial is one evaluation (2.4 us) plus solve,
+// exponential and bookkeeping (2.2 us).  One host core running the same loop in plain C (oracle/pose_lm_oracle.c) takes
+// 102 / 372 / 576 / 2728 us at 50 / 200 / 256 / 1000 edges: at the reference's frame size (<= 200 edges, slam.py:23)
+// a single refinement gains nothing from the GPU; the batch form below (one workgroup per frame) is where it does:
+// 16 frames x 200 edges in 0.68 ms = 42 us per frame.
+//
 // Same structure and constants as slamhip/pose_opt.py (the host-driven version
 // the tests compare against): every round restarts from the input pose
 // (frontend.py:360), chi2 > threshold marks an edge as outlier / level 1
@@ -33,7 +44,7 @@ struct po_params {
 };
 
 // exp([w, v]) * T for a 3x4 row-major pose (rotation first, g2o SE3Quat::exp ordering)
-__device__ void po_apply_update(const double* dx, const double* T, double* Tn) {
+__device__ __forceinline__ void po_apply_update(const double* dx, const double* T, double* Tn) {
     const double wx = dx[0], wy = dx[1], wz = dx[2];
     const double th2 = wx * wx + wy * wy + wz * wz, th = sqrt(th2);
     double a, b, c;  // sin(th)/th, (1-cos)/th^2, (th-sin)/th^3
@@ -45,17 +56,23 @@ __device__ void po_apply_update(const double* dx, const double* T, double* Tn) {
     }
     const double W[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
     double W2[9];
+#pragma unroll
     for (int i = 0; i < 3; i++)
+#pragma unroll
         for (int j = 0; j < 3; j++) W2[i * 3 + j] = W[i * 3] * W[j] + W[i * 3 + 1] * W[3 + j] + W[i * 3 + 2] * W[6 + j];
     double R[9], V[9];
+#pragma unroll
     for (int i = 0; i < 9; i++) {
         const double I = (i % 4 == 0) ? 1.0 : 0.0;
         R[i] = I + a * W[i] + b * W2[i];
         V[i] = I + b * W[i] + c * W2[i];
     }
     double t[3];
+#pragma unroll
     for (int i = 0; i < 3; i++) t[i] = V[i * 3] * dx[3] + V[i * 3 + 1] * dx[4] + V[i * 3 + 2] * dx[5];
+#pragma unroll
     for (int i = 0; i < 3; i++) {
+#pragma unroll
         for (int j = 0; j < 4; j++)
             Tn[i * 4 + j] = R[i * 3] * T[j] + R[i * 3 + 1] * T[4 + j] + R[i * 3 + 2] * T[8 + j];
         Tn[i * 4 + 3] += t[i];
@@ -64,7 +81,7 @@ __device__ void po_apply_update(const double* dx, const double* T, double* Tn) {
 
 // solve (H + lam I) x = -b by LDL^T (six reciprocals, no square roots: this runs on one lane, so the length of
 // the dependent f64 chain is what it costs); H given as packed upper triangle s[0..20]; false if not SPD
-__device__ bool po_solve(const double* s, const double* b, double lam, double* x) {
+__device__ __forceinline__ bool po_solve(const double* s, const double* b, double lam, double* x) {
     double A[36];
     int t = 0;
 #pragma unroll
@@ -282,10 +299,15 @@ __global__ __launch_bounds__(PO_THREADS) void pose_opt_kernel(const double* __re
                                                               const int* __restrict__ offsets, po_cam cam,
                                                               po_params prm, double* __restrict__ pose_out,
                                                               uint8_t* __restrict__ g_active,
-                                                              double* __restrict__ g_chi2, int* __restrict__ stats) {
+                                                              double* __restrict__ g_chi2, int* __restrict__ stats,
+                                                              unsigned int* __restrict__ index_errors) {
     if (offsets) {
-        const int b = blockIdx.x, first = offsets[b];
-        O = offsets[b + 1] - first;
+        // O is the length of the concatenated arrays here.  A table that is not ascending or leaves [0, O] is the
+        // caller's bug; it is reported (slam_index_errors) and the frame shrinks to what lies inside, never a wild access.
+        const int b = blockIdx.x, total = O, lo = offsets[b], hi = offsets[b + 1];
+        const int first = min(max(lo, 0), total), last = min(max(hi, first), total);
+        if ((first != lo || last != hi) && threadIdx.x == 0) atomicAdd(index_errors, 1u);
+        O = last - first;
         pose_in += 12 * b; pose_out += 12 * b; stats += 2 * b;
         g_points += 3 * (size_t)first; g_meas += first; g_active += first; g_chi2 += first;
     }
@@ -329,7 +351,7 @@ extern "C" int slam_pose_optimize_f64(slam_ctx* ctx, const double* d_pose_in, co
     const po_cam cam = {fx, fy, cx, cy};
     const po_params prm = {rounds, iterations, chi2_threshold, huber_delta};
     pose_opt_kernel<<<1, PO_THREADS, 0, ctx->stream>>>(d_pose_in, d_points, (const double2*)d_meas, (int)O, nullptr, cam, prm,
-                                                       d_pose_out, d_inlier, d_chi2, d_stats);
+                                                       d_pose_out, d_inlier, d_chi2, d_stats, slam_index_error_counter(ctx));
     SLAM_HIP(hipGetLastError());
     return SLAM_OK;
 }
@@ -349,8 +371,8 @@ extern "C" int slam_pose_optimize_batch_f64(slam_ctx* ctx, int64_t B, const doub
     SLAM_HIP(hipSetDevice(ctx->device));
     const po_cam cam = {fx, fy, cx, cy};
     const po_params prm = {rounds, iterations, chi2_threshold, huber_delta};
-    pose_opt_kernel<<<(unsigned)B, PO_THREADS, 0, ctx->stream>>>(d_pose_in, d_points, (const double2*)d_meas, 0, d_offsets, cam, prm,
-                                                                 d_pose_out, d_inlier, d_chi2, d_stats);
+    pose_opt_kernel<<<(unsigned)B, PO_THREADS, 0, ctx->stream>>>(d_pose_in, d_points, (const double2*)d_meas, (int)O_total, d_offsets, cam, prm,
+                                                                 d_pose_out, d_inlier, d_chi2, d_stats, slam_index_error_counter(ctx));
     SLAM_HIP(hipGetLastError());
     return SLAM_OK;
 }

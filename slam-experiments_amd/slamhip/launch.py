@@ -5,9 +5,15 @@ from a launcher: the ranks' identities, a way to ship small objects between them
 handles, verdicts, timings) and a barrier.  This module provides them:
 
 * ``Rendezvous``: rank 0 serves an abstract-namespace Unix socket; every rank (rank 0 included) connects to it and
-  all collectives are one primitive, ``allgather(obj)``: each rank sends one pickled object, the server answers
-  with the list of all of them.  ``bcast`` and ``barrier`` are built on it.  Every wait is bounded: a peer that
-  died or took another code path turns into a ``RendezvousError`` naming the missing ranks, not a hang.
+  all collectives are one primitive, ``allgather(obj)``: each rank sends one object, the server answers with the
+  list of all of them.  ``bcast`` and ``barrier`` are built on it.  Every wait is bounded: a peer that died or took
+  another code path turns into a ``RendezvousError`` naming the missing ranks, not a hang.
+  An abstract socket has no file permissions, so the server trusts nobody by default: a peer must run under the
+  same uid (``SO_PEERCRED``), open with a fixed-layout hello (magic, world, rank, a 32-byte token) and present the
+  run's random token (``spawn_ranks`` hands it down in the environment; under ``torch.distributed.run`` rank 0
+  leaves it in a 0600 file that only the same user can read); ranks outside ``[0, world)`` and duplicates are
+  turned away.  Clients check the server's uid the same way.  Nothing on the wire is ever unpickled: objects
+  travel in a small tagged encoding (None / bool / int / float / str / bytes / list / tuple / dict / numpy array).
 * ``spawn_ranks``: start ``world`` copies of a script as child processes (RANK / LOCAL_RANK / WORLD_SIZE /
   SLAM_RDZV in their environment) from a parent that never touches the GPU, forward rank 0's stdout, return the
   worst exit code.
@@ -17,12 +23,15 @@ handles, verdicts, timings) and a barrier.  This module provides them:
 """
 from __future__ import annotations
 
+import hmac
 import os
-import pickle
+import secrets
 import socket
+import stat
 import struct
 import subprocess
 import sys
+import tempfile
 import threading
 import time
 from typing import List, Optional, Sequence, Tuple
@@ -36,50 +45,249 @@ def _address(name: str) -> str:
     return "\0slamhip-" + name          # abstract namespace: no file to clean up, private to this network namespace
 
 
+_MAGIC = b"SLRZ"
+_HELLO = struct.Struct("<4sIi32s")            # magic, world, rank, token
+_MAX_FRAME = 1 << 31
+
+
+def _enc(obj, out: bytearray) -> None:
+    """Tagged binary encoding of the plain objects the ranks exchange (no code travels, nothing is unpickled)."""
+    import numpy as np
+
+    if obj is None:
+        out += b"N"
+    elif obj is True or obj is False:
+        out += b"T" if obj else b"F"
+    elif isinstance(obj, (int, np.integer)):
+        out += b"i" + struct.pack("<q", int(obj))
+    elif isinstance(obj, (float, np.floating)):
+        out += b"d" + struct.pack("<d", float(obj))
+    elif isinstance(obj, str):
+        b = obj.encode("utf-8")
+        out += b"s" + struct.pack("<Q", len(b)) + b
+    elif isinstance(obj, (bytes, bytearray, memoryview)):
+        b = bytes(obj)
+        out += b"b" + struct.pack("<Q", len(b)) + b
+    elif isinstance(obj, (list, tuple)):
+        out += (b"l" if isinstance(obj, list) else b"t") + struct.pack("<Q", len(obj))
+        for x in obj:
+            _enc(x, out)
+    elif isinstance(obj, dict):
+        out += b"m" + struct.pack("<Q", len(obj))
+        for k, v in obj.items():
+            _enc(k, out)
+            _enc(v, out)
+    else:
+        raise TypeError(f"{type(obj).__name__} cannot cross the rendezvous")
+
+
+def _dec(buf: memoryview, pos: int):
+    tag = bytes(buf[pos:pos + 1])
+    pos += 1
+    if tag == b"N":
+        return None, pos
+    if tag in (b"T", b"F"):
+        return tag == b"T", pos
+    if tag == b"i":
+        return struct.unpack_from("<q", buf, pos)[0], pos + 8
+    if tag == b"d":
+        return struct.unpack_from("<d", buf, pos)[0], pos + 8
+    if tag in (b"s", b"b"):
+        n = struct.unpack_from("<Q", buf, pos)[0]
+        pos += 8
+        if n > len(buf) - pos:
+            raise ValueError("truncated rendezvous frame")
+        raw = bytes(buf[pos:pos + n])
+        return (raw.decode("utf-8") if tag == b"s" else raw), pos + n
+    if tag in (b"l", b"t"):
+        n = struct.unpack_from("<Q", buf, pos)[0]
+        pos += 8
+        items = []
+        for _ in range(n):
+            if pos >= len(buf):
+                raise ValueError("truncated rendezvous frame")
+            x, pos = _dec(buf, pos)
+            items.append(x)
+        return (items if tag == b"l" else tuple(items)), pos
+    if tag == b"m":
+        n = struct.unpack_from("<Q", buf, pos)[0]
+        pos += 8
+        d = {}
+        for _ in range(n):
+            k, pos = _dec(buf, pos)
+            v, pos = _dec(buf, pos)
+            d[k] = v
+        return d, pos
+    raise ValueError(f"unknown tag {tag!r} in a rendezvous frame")
+
+
+def dumps(obj) -> bytes:
+    """Encode ``obj`` for the wire.  numpy arrays are wrapped as {"__nd__": [dtype, shape, bytes]}."""
+    import numpy as np
+
+    def wrap(x):
+        if isinstance(x, np.ndarray):
+            a = np.ascontiguousarray(x)
+            if a.dtype.hasobject:
+                raise TypeError("object arrays cannot cross the rendezvous")
+            return {"__nd__": [a.dtype.str, list(a.shape), a.tobytes()]}
+        if isinstance(x, list):
+            return [wrap(v) for v in x]
+        if isinstance(x, tuple):
+            return tuple(wrap(v) for v in x)
+        if isinstance(x, dict):
+            return {k: wrap(v) for k, v in x.items()}
+        return x
+
+    out = bytearray()
+    _enc(wrap(obj), out)
+    return bytes(out)
+
+
+def loads(blob: bytes):
+    import numpy as np
+
+    def unwrap(x):
+        if isinstance(x, dict):
+            if set(x) == {"__nd__"}:
+                dt, shape, raw = x["__nd__"]
+                dtype = np.dtype(dt)
+                if dtype.hasobject:
+                    raise ValueError("object arrays cannot cross the rendezvous")
+                return np.frombuffer(raw, dtype=dtype).reshape(shape).copy()
+            return {k: unwrap(v) for k, v in x.items()}
+        if isinstance(x, list):
+            return [unwrap(v) for v in x]
+        if isinstance(x, tuple):
+            return tuple(unwrap(v) for v in x)
+        return x
+
+    obj, pos = _dec(memoryview(blob), 0)
+    if pos != len(blob):
+        raise ValueError("trailing bytes in a rendezvous frame")
+    return unwrap(obj)
+
+
 def _send(sock: socket.socket, obj) -> None:
-    blob = pickle.dumps(obj, protocol=pickle.HIGHEST_PROTOCOL)      # our own objects between our own processes
+    blob = dumps(obj)
     sock.sendall(struct.pack("<Q", len(blob)) + blob)
+
+
+def _recv_exact(sock: socket.socket, need: int) -> bytes:
+    buf = bytearray()
+    while len(buf) < need:
+        chunk = sock.recv(min(1 << 20, need - len(buf)))
+        if not chunk:
+            raise EOFError("peer closed the rendezvous connection")
+        buf += chunk
+    return bytes(buf)
 
 
 def _recv(sock: socket.socket, timeout: float):
     """One framed object, or EOFError if the peer closed, or socket.timeout."""
     sock.settimeout(timeout)
-    buf = bytearray()
-    need = 8
-    header = True
+    need = struct.unpack("<Q", _recv_exact(sock, 8))[0]
+    if need > _MAX_FRAME:
+        raise ValueError(f"rendezvous frame of {need} bytes refused")
+    return loads(_recv_exact(sock, need))
+
+
+def _peer_uid(sock: socket.socket) -> int:
+    """uid of the process at the other end of a Unix socket (SO_PEERCRED: pid, uid, gid)."""
+    cred = sock.getsockopt(socket.SOL_SOCKET, socket.SO_PEERCRED, struct.calcsize("3i"))
+    return struct.unpack("3i", cred)[1]
+
+
+def _token_path(name: str) -> str:
+    safe = "".join(ch if ch.isalnum() or ch in "-_." else "_" for ch in name)
+    return os.path.join(os.environ.get("XDG_RUNTIME_DIR") or tempfile.gettempdir(), f"slamhip-rdzv-{os.getuid()}-{safe}.token")
+
+
+def _publish_token(name: str) -> Tuple[bytes, str]:
+    """Rank 0 under an external launcher: a fresh random token in a file only this user can read."""
+    path = _token_path(name)
+    try:
+        os.unlink(path)                      # a stale file of an earlier run of ours (someone else's cannot be removed
+    except FileNotFoundError:                # from a sticky directory, and then O_EXCL below fails loudly)
+        pass
+    token = secrets.token_bytes(32)
+    fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_EXCL | getattr(os, "O_NOFOLLOW", 0), 0o600)
+    with os.fdopen(fd, "wb") as f:
+        f.write(token)
+    return token, path
+
+
+def _read_token(name: str, timeout: float) -> bytes:
+    path = _token_path(name)
+    deadline = time.monotonic() + timeout
     while True:
-        while len(buf) < need:
-            chunk = sock.recv(min(1 << 20, need - len(buf)))
-            if not chunk:
-                raise EOFError("peer closed the rendezvous connection")
-            buf += chunk
-        if header:
-            need, header = struct.unpack("<Q", bytes(buf))[0], False
-            buf = bytearray()
-            if need == 0:
-                return None
-        else:
-            return pickle.loads(bytes(buf))
+        try:
+            fd = os.open(path, os.O_RDONLY | getattr(os, "O_NOFOLLOW", 0))
+            try:
+                st = os.fstat(fd)
+                if st.st_uid != os.getuid() or stat.S_IMODE(st.st_mode) & 0o077 or not stat.S_ISREG(st.st_mode):
+                    raise RendezvousError(f"{path} is not a private file of uid {os.getuid()}: refusing its token")
+                tok = os.read(fd, 64)
+            finally:
+                os.close(fd)
+            if len(tok) == 32:
+                return tok
+        except FileNotFoundError:
+            pass
+        if time.monotonic() > deadline:
+            raise RendezvousError(f"no rendezvous token at {path} after {timeout:.0f} s")
+        time.sleep(0.02)
 
 
 class _Server(threading.Thread):
-    """Rank 0's side: accept `world` connections, then serve rounds of all-gather until every rank has said goodbye."""
+    """Rank 0's side: accept `world` authenticated connections, then serve rounds of all-gather until every rank has
+    said goodbye.  A connection that fails the checks (foreign uid, wrong magic / world / token, rank out of range or
+    already taken) is closed and ignored: it cannot join, and it cannot stop the real ranks from joining."""
 
-    def __init__(self, name: str, world: int, timeout: float):
+    def __init__(self, name: str, world: int, timeout: float, token: bytes):
         super().__init__(daemon=True)
-        self.world, self.timeout = world, timeout
+        self.world, self.timeout, self.token = world, timeout, token
         self.sock = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
-        self.sock.bind(_address(name))
-        self.sock.listen(world)
+        try:
+            self.sock.bind(_address(name))
+        except OSError as exc:
+            self.sock.close()
+            raise RendezvousError(f"rendezvous name '{name}' is already taken on this host ({exc})") from None
+        self.sock.listen(max(world, 8))
         self.error: Optional[str] = None
+        self.rejected: List[str] = []
+
+    def _admit(self, c: socket.socket, conns: dict) -> None:
+        try:
+            if _peer_uid(c) != os.getuid():
+                raise ValueError(f"peer runs under uid {_peer_uid(c)}")
+            c.settimeout(min(self.timeout, 10.0))
+            magic, world, rank, token = _HELLO.unpack(_recv_exact(c, _HELLO.size))
+            if magic != _MAGIC or world != self.world:
+                raise ValueError("not a hello of this run")
+            if not hmac.compare_digest(token, self.token):
+                raise ValueError("wrong token")
+            if not 0 <= rank < self.world or rank in conns:
+                raise ValueError(f"rank {rank} is out of range or already connected")
+            c.sendall(_MAGIC)                         # admitted
+            conns[rank] = c
+        except (ValueError, OSError, EOFError, struct.error) as exc:
+            self.rejected.append(str(exc))
+            c.close()
 
     def run(self) -> None:
         conns = {}
         try:
-            self.sock.settimeout(self.timeout)
+            deadline = time.monotonic() + self.timeout
             while len(conns) < self.world:
-                c, _ = self.sock.accept()
-                conns[_recv(c, self.timeout)] = c
+                self.sock.settimeout(max(0.01, deadline - time.monotonic()))
+                try:
+                    c, _ = self.sock.accept()
+                except socket.timeout:
+                    missing = sorted(set(range(self.world)) - set(conns))
+                    raise RendezvousError(f"ranks {missing} did not join within {self.timeout:.0f} s"
+                                          + (f" (turned away: {self.rejected})" if self.rejected else "")) from None
+                self._admit(c, conns)
             while conns:
                 items, gone = {}, []
                 deadline = time.monotonic() + self.timeout
@@ -119,14 +327,28 @@ class _Server(threading.Thread):
 class Rendezvous:
     """One per process.  ``name`` must be the same on all ranks of a run and unique among concurrent runs."""
 
-    def __init__(self, rank: int, world: int, name: str, timeout: float = 180.0):
+    def __init__(self, rank: int, world: int, name: str, timeout: float = 180.0, token: Optional[bytes] = None):
         self.rank, self.world, self.timeout = rank, world, timeout
         self._server = None
         self._conn: Optional[socket.socket] = None
+        self._token_file: Optional[str] = None
         if world <= 1:
             return
+        if not 0 <= rank < world:
+            raise RendezvousError(f"rank {rank} outside [0, {world})")
+        # the run's shared secret: handed down by spawn_ranks (SLAM_RDZV_TOKEN), given by the caller, or - under an
+        # external launcher such as torch.distributed.run - published by rank 0 in a file private to this user
+        if token is None and os.environ.get("SLAM_RDZV_TOKEN"):
+            token = bytes.fromhex(os.environ["SLAM_RDZV_TOKEN"])
+        if token is None:
+            if rank == 0:
+                token, self._token_file = _publish_token(name)
+            else:
+                token = _read_token(name, timeout)
+        if len(token) != 32:
+            raise RendezvousError("the rendezvous token must be 32 bytes")
         if rank == 0:
-            self._server = _Server(name, world, timeout)
+            self._server = _Server(name, world, timeout, token)
             self._server.start()
         deadline = time.monotonic() + timeout
         while True:
@@ -140,7 +362,19 @@ class Rendezvous:
                 if time.monotonic() > deadline:
                     raise RendezvousError(f"rank {rank}: no rendezvous server '{name}' after {timeout:.0f} s") from None
                 time.sleep(0.02)
-        _send(self._conn, rank)
+        if _peer_uid(self._conn) != os.getuid():
+            self._conn.close()
+            self._conn = None
+            raise RendezvousError(f"rank {rank}: the rendezvous server '{name}' belongs to another user")
+        self._conn.sendall(_HELLO.pack(_MAGIC, world, rank, token))
+        try:
+            self._conn.settimeout(timeout)
+            if _recv_exact(self._conn, 4) != _MAGIC:
+                raise EOFError("bad acknowledgement")
+        except (EOFError, OSError) as exc:
+            self._conn.close()
+            self._conn = None
+            raise RendezvousError(f"rank {rank}: the rendezvous server turned this rank away ({exc})") from None
 
     def allgather(self, obj) -> list:
         """[obj of rank 0, obj of rank 1, ...] on every rank.  Every rank must make the same sequence of calls."""
@@ -174,6 +408,12 @@ class Rendezvous:
         if self._server is not None:
             self._server.join(self.timeout)
             self._server = None
+        if self._token_file:
+            try:
+                os.unlink(self._token_file)
+            except OSError:
+                pass
+            self._token_file = None
 
 
 def from_env(env=os.environ) -> Tuple[int, int, int, Optional[str]]:
@@ -193,9 +433,10 @@ def spawn_ranks(script: str, args: Sequence[str], world: int, env_extra: Optiona
     """Run ``python script args...`` as ``world`` rank processes and wait for them.  The caller must not have
     touched the GPU (children are separate processes started with a fresh interpreter, not forks of GPU state)."""
     name = f"spawn-{os.getpid()}-{time.monotonic_ns()}"
+    token = secrets.token_hex(32)           # the run's shared secret: only these children get it
     procs: List[subprocess.Popen] = []
     for r in range(world):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), SLAM_RDZV=name,
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), SLAM_RDZV=name, SLAM_RDZV_TOKEN=token,
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         env.update(env_extra or {})
         procs.append(subprocess.Popen([sys.executable, script, *args], env=env,

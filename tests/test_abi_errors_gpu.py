@@ -210,3 +210,33 @@ def test_out_of_range_indices_are_reported_not_dereferenced(gpu_ctx):
         assert lib.slam_index_errors(ctx.handle, ctypes.byref(cnt)) == 0 and cnt.value == 0
     for b in (*d, e, Jp, Jq):
         b.free()
+
+
+def test_batch_pose_refinement_with_a_bad_offsets_table_is_reported_not_dereferenced(gpu_ctx):
+    """slam_pose_optimize_batch_f64 with a table that is not ascending / leaves [0, O_total]: no access outside the
+    arrays (the frames shrink to what lies inside), the per-context counter says how many frames were affected, and
+    the frames of a correct table next to them are refined as usual."""
+    import ctypes
+
+    ctx, lib = gpu_ctx, gpu_ctx.lib
+    rng = np.random.default_rng(5)
+    O = 300
+    X = np.c_[rng.uniform(-4, 4, (O, 2)), rng.uniform(6, 15, O)]
+    meas = np.c_[458.654 * X[:, 0] / X[:, 2] + 367.215, 457.296 * X[:, 1] / X[:, 2] + 248.375]
+    pose = np.tile(np.eye(4)[:3, :4].reshape(12), (4, 1))
+    bufs = [ctx.upload(pose), ctx.upload(X), ctx.upload(meas), ctx.malloc(4 * 96), ctx.malloc(O), ctx.malloc(O * 8), ctx.malloc(32)]
+    d_pose, d_pts, d_mes, d_out, d_inl, d_chi, d_st = bufs
+    n = ctypes.c_int64(-1)
+    assert lib.slam_index_errors(ctx.handle, ctypes.byref(n)) == 0          # clear
+    for table, bad_frames in (([0, 100, 200, 250, 300], 0), ([0, 100, 50, 400, 300], 3), ([-7, 100, 200, 1 << 30, 300], 3)):
+        d_off = ctx.upload(np.array(table, np.int32))
+        assert lib.slam_pose_optimize_batch_f64(ctx.handle, 4, d_pose.ptr, d_pts.ptr, d_mes.ptr, d_off.ptr, O, 458.654, 457.296,
+                                                367.215, 248.375, 4, 10, 5.991 ** 2, 1.0, d_out.ptr, d_inl.ptr, d_chi.ptr,
+                                                d_st.ptr) == 0
+        ctx.sync()
+        assert lib.slam_index_errors(ctx.handle, ctypes.byref(n)) == 0 and n.value == bad_frames, (table, n.value)
+        st = d_st.download(np.int32, (4, 2))
+        assert st[0, 0] == min(max(table[1], 0), O) - max(table[0], 0)      # frame 0 is sane in every table: all inliers
+        d_off.free()
+    for b in bufs:
+        b.free()

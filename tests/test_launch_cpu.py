@@ -53,3 +53,124 @@ def test_launcher_module_imports_no_framework():
     code = ("import sys; sys.path.insert(0, %r); import slamhip.launch, slamhip.dist; "
             "assert 'torch' not in sys.modules and 'mpi4py' not in sys.modules") % os.path.join(ROOT, "slam-experiments_amd")
     assert subprocess.run([sys.executable, "-c", code]).returncode == 0
+
+
+def test_wire_codec_round_trips_plain_objects_and_refuses_the_rest():
+    import numpy as np
+    import pytest
+    from slamhip import launch
+
+    objs = [None, True, False, 0, -(2 ** 62), 1.5, "text", b"\x00\xff" * 64, [1, (2.0, "x"), {"k": b"v"}],
+            {"rank": 3, "blob": bytes(1000)}, (np.arange(12, dtype=np.int32).reshape(3, 4), np.zeros(0, np.uint8))]
+    for o in objs:
+        r = launch.loads(launch.dumps(o))
+        if isinstance(o, tuple) and isinstance(o[0], np.ndarray):
+            assert all(a.dtype == b.dtype and a.shape == b.shape and np.array_equal(a, b) for a, b in zip(o, r))
+        else:
+            assert r == o and type(r) is type(o)
+    for bad in (object(), {1, 2}, np.array([object()], dtype=object), lambda: 0):
+        with pytest.raises(TypeError):
+            launch.dumps(bad)
+    import pickle
+    for junk in (pickle.dumps({"a": 1}), b"", b"Zjunk", launch.dumps([1, 2])[:-3], launch.dumps(1) + b"x"):
+        with pytest.raises((ValueError, struct_error(), IndexError)):
+            launch.loads(junk)
+
+
+def struct_error():
+    import struct
+    return struct.error
+
+
+def test_server_turns_away_strangers_and_still_admits_the_real_ranks():
+    """A local process that knows the socket name but not the token (or claims a bad rank) cannot join, cannot make
+    the server unpickle anything, and does not stop the real ranks (launch.py)."""
+    import pickle
+    import socket
+    import threading
+    from slamhip import launch
+
+    name = f"test-auth-{os.getpid()}-{time.monotonic_ns()}"
+    token = os.urandom(32)
+    out = {}
+
+    def rank(r):
+        rz = launch.Rendezvous(r, 2, name, timeout=20, token=token)
+        out[r] = rz.allgather(("hello", r))
+        rz.close()
+
+    t0 = threading.Thread(target=rank, args=(0,))
+    t0.start()
+    time.sleep(0.3)                                   # server is up, waiting for rank 1
+    # 1) a pickle bomb where the hello should be
+    c = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+    c.connect(launch._address(name))
+    c.sendall(pickle.dumps(os.system) + b"\0" * 64)
+    # 2) right layout, wrong token
+    d = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+    d.connect(launch._address(name))
+    d.sendall(launch._HELLO.pack(launch._MAGIC, 2, 1, b"\x01" * 32))
+    # 3) right token, impossible rank / duplicate rank
+    for bad_rank in (7, -1, 0):
+        e = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+        e.connect(launch._address(name))
+        e.sendall(launch._HELLO.pack(launch._MAGIC, 2, bad_rank, token))
+        e.settimeout(5)
+        assert e.recv(4) == b""                       # closed without an acknowledgement
+        e.close()
+    for s in (c, d):
+        s.settimeout(5)
+        try:
+            assert s.recv(4) == b""                   # closed ...
+        except ConnectionResetError:
+            pass                                      # ... or reset (the server left part of the junk unread)
+        s.close()
+    t1 = threading.Thread(target=rank, args=(1,))
+    t1.start()
+    t0.join(30)
+    t1.join(30)
+    assert out == {0: [("hello", 0), ("hello", 1)], 1: [("hello", 0), ("hello", 1)]}
+
+
+def test_external_launcher_token_file_is_private_and_removed():
+    """Under torch.distributed.run no token is handed down: rank 0 publishes one in a 0600 file, the others read it
+    only if it is a private regular file of the same user."""
+    import stat
+    import threading
+    import pytest
+    from slamhip import launch
+
+    name = f"test-file-{os.getpid()}-{time.monotonic_ns()}"
+    env_had = os.environ.pop("SLAM_RDZV_TOKEN", None)
+    try:
+        res = {}
+
+        def rank(r):
+            rz = launch.Rendezvous(r, 2, name, timeout=20)
+            if r == 0:
+                st = os.stat(launch._token_path(name))
+                res["mode"] = stat.S_IMODE(st.st_mode)
+            res[r] = rz.bcast(b"id" * 64 if r == 0 else None)
+            rz.barrier()
+            rz.close()
+
+        ts = [threading.Thread(target=rank, args=(r,)) for r in (0, 1)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(30)
+        assert res[0] == res[1] == b"id" * 64 and res["mode"] == 0o600
+        assert not os.path.exists(launch._token_path(name))
+        # a token file readable by others is refused
+        other = f"test-perm-{os.getpid()}-{time.monotonic_ns()}"
+        with open(launch._token_path(other), "wb") as f:
+            f.write(b"\x02" * 32)
+        os.chmod(launch._token_path(other), 0o644)
+        try:
+            with pytest.raises(launch.RendezvousError):
+                launch._read_token(other, 0.2)
+        finally:
+            os.unlink(launch._token_path(other))
+    finally:
+        if env_had is not None:
+            os.environ["SLAM_RDZV_TOKEN"] = env_had

@@ -186,3 +186,33 @@ def test_pose_normal_equations_oracle():
         bref = np.einsum("o,oia,oi->a", w, J, e)
         assert np.allclose(H, Href, rtol=1e-12) and np.allclose(b, bref, rtol=1e-12)
         assert np.allclose(chi2, (e**2).sum(1), rtol=1e-13)
+
+
+def test_pose_lm_c_and_numpy_statements_agree():
+    """oracle/pose_lm_oracle.c (Gaussian elimination, series exponential; the CPU baseline of the pose refinement) and
+    oracle.pose_lm_np (numpy solve, scipy expm) restate Frontend._correct_current_pose (frontend.py:298-393)
+    independently: same pose to 1e-9, the same inlier sets, chi2 to 1e-7, on frames with gross outliers, other
+    schedules, the empty frame and a frame whose every edge is an outlier."""
+    from scipy.spatial.transform import Rotation
+
+    FX, FY, CX, CY = 458.654, 457.296, 367.215, 248.375
+    for seed, O, rounds, iters, thr, delta in ((228, 200, 4, 10, 5.991 ** 2, 1.0), (1, 64, 4, 10, 5.991 ** 2, 1.0),
+                                               (2, 700, 2, 3, 9.0, 0.0), (3, 12, 4, 10, 5.991, 2.5), (4, 150, 3, 1, 35.89, 1.0)):
+        rng = np.random.default_rng(seed)
+        T = np.eye(4)
+        T[:3, :3] = Rotation.from_rotvec(rng.uniform(-0.15, 0.15, 3)).as_matrix()
+        T[:3, 3] = rng.uniform(-0.5, 0.5, 3)
+        X = np.c_[rng.uniform(-4, 4, (O, 2)), rng.uniform(6, 15, O)]
+        pc = X @ T[:3, :3].T + T[:3, 3]
+        meas = np.c_[FX * pc[:, 0] / pc[:, 2] + CX, FY * pc[:, 1] / pc[:, 2] + CY] + rng.normal(0, 0.4, (O, 2))
+        meas[::7] += rng.uniform(40, 120, (len(meas[::7]), 2))
+        meas = meas.astype(np.int32).astype(np.float64)
+        T_init = oracle.se3_exp_np(rng.normal(0, 0.02, 6)) @ T
+        Tn, inl_n, chi_n, acc_n = oracle.pose_lm_np(T_init, X, meas, FX, FY, CX, CY, rounds, iters, thr, delta)
+        Tc, inl_c, chi_c, acc_c = oracle.pose_lm_c(T_init[:3, :4], X, meas, FX, FY, CX, CY, rounds, iters, thr, delta)
+        assert np.allclose(Tc.reshape(3, 4), Tn[:3, :4], rtol=0, atol=1e-9), (seed, np.abs(Tc.reshape(3, 4) - Tn[:3, :4]).max())
+        assert np.array_equal(inl_c, inl_n) and np.allclose(chi_c, chi_n, rtol=1e-7, atol=1e-7)
+        assert abs(acc_c - acc_n) <= 8
+    # no edges: the pose comes back unchanged, no inliers
+    Tc, inl_c, _, acc = oracle.pose_lm_c(np.eye(4)[:3, :4], np.zeros((0, 3)), np.zeros((0, 2)), FX, FY, CX, CY)
+    assert np.array_equal(Tc.reshape(3, 4), np.eye(4)[:3, :4]) and inl_c.size == 0 and acc == 0

@@ -75,3 +75,39 @@ t0 = time.perf_counter()
 for _ in range(10):
     be.optimize_poses(np.stack(ps), [X] * 16, [pix] * 16, 458.654, 457.296, 367.215, 248.375)
 print(f"optimize_poses 16 frames x 200 edges, one launch: {(time.perf_counter() - t0) / 10 * 1e3:7.3f} ms per call ({(time.perf_counter() - t0) / 160 * 1e3:.3f} ms per frame)")
+
+# The pose refinement beside a plain C loop on ONE host core (oracle/pose_lm_oracle.c; test infrastructure, the CPU baseline of
+# this path: the reference runs it as g2o C++ calling back into Python per edge, frontend.py:272-291) and the kernel's own time.
+import ctypes
+sys.path.insert(0, ROOT)
+from oracle import oracle
+ctx = be.ctx
+lib = ctx.lib
+for O in (50, 200, 256, 257, 1000):
+    Xo = np.c_[rng.uniform(-4, 4, (O, 2)), rng.uniform(6, 15, O)]
+    po = np.c_[458.654 * Xo[:, 0] / Xo[:, 2] + 367.215, 457.296 * Xo[:, 1] / Xo[:, 2] + 248.375] + rng.normal(0, 0.3, (O, 2))
+    po[::9] += 70.0
+    po = po.astype(np.int32).astype(np.float64)
+    p12 = np.ascontiguousarray(T0[:3, :4].reshape(12))
+    oracle.pose_lm_c(p12, Xo, po, 458.654, 457.296, 367.215, 248.375)
+    t0 = time.perf_counter()
+    for _ in range(50):
+        Tc, inl_c, _, acc_c = oracle.pose_lm_c(p12, Xo, po, 458.654, 457.296, 367.215, 248.375)
+    cpu_ms = (time.perf_counter() - t0) / 50 * 1e3
+    d = [ctx.upload(p12), ctx.upload(Xo), ctx.upload(po), ctx.malloc(96), ctx.malloc(O), ctx.malloc(O * 8), ctx.malloc(8)]
+    call = lambda: lib.slam_pose_optimize_f64(ctx.handle, d[0].ptr, d[1].ptr, d[2].ptr, O, 458.654, 457.296, 367.215, 248.375, 4, 10,
+                                              5.991 ** 2, 1.0, d[3].ptr, d[4].ptr, d[5].ptr, d[6].ptr)
+    for _ in range(5):
+        assert call() == 0
+    ctx.sync()
+    ctx.timer_start()
+    for _ in range(50):
+        call()
+    dev_ms = ctx.timer_stop() / 50
+    got = d[3].download(np.float64, (12,))
+    st = d[6].download(np.int32, (2,))
+    same = bool(np.array_equal(d[4].download(np.uint8, (O,)).astype(bool), inl_c))
+    print(f"pose refinement {O:5d} edges: device {dev_ms * 1e3:7.1f} us per launch ({st[1]} accepted steps) | plain C on one host core "
+          f"{cpu_ms * 1e3:7.1f} us ({acc_c} steps) | max pose difference {np.abs(got - Tc).max():.1e}, same inlier set: {same}")
+    for b in d:
+        b.free()

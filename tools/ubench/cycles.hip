@@ -88,6 +88,30 @@ __global__ __launch_bounds__(256) void k(uint32_t* out, stamp* st, int iters) {
         if (MODE == 25) { asm volatile(X4("s_setprio 0\n" XOR8 XOR8_B "s_setprio 2\n" BCNT16_2ROWS "s_setprio 0\n" XOR8 XOR8_B "s_setprio 2\n" BCNT16_2ROWS) ::: CLOB); it += 7; }
         if (MODE == 26) { asm volatile(X4(X4("s_setprio 2\n" XOR8 "s_setprio 0\n" BCNT8)) ::: CLOB); it += 7; }
         if (MODE == 27) { asm volatile(X4(X4("s_setprio 0\n" XOR8 "s_setprio 3\n" BCNT8 AND1)) ::: CLOB); it += 7; }
+        if (MODE == 28 || MODE == 29 || MODE == 30) {
+            // the kernel's row with priorities: reads of the NEXT row are issued first (rolling, two 8-register buffers:
+            // v24-31 / v12-15,v44-47 would need renaming per row, so here both rows xor out of place into v32-39, which keeps
+            // the instruction mix and the LDS traffic of the kernel: 2 ds_read_b128 per 16 (MODE 28), per 32 (MODE 29: two
+            // queries per lane) VALU instructions; MODE 30 = MODE 28 without the reads (same waits removed)
+            if (MODE == 28)
+                asm volatile(X4("ds_read_b128 v[24:27], %0\n ds_read_b128 v[28:31], %0 offset:16\n s_waitcnt lgkmcnt(2)\n"
+                                "s_setprio 0\n" XOR8 "s_setprio 2\n" BCNT8 AND1
+                                "ds_read_b128 v[24:27], %0 offset:32\n ds_read_b128 v[28:31], %0 offset:48\n s_waitcnt lgkmcnt(2)\n"
+                                "s_setprio 0\n" XOR8 "s_setprio 2\n" BCNT8 AND1
+                                "ds_read_b128 v[24:27], %0 offset:64\n ds_read_b128 v[28:31], %0 offset:80\n s_waitcnt lgkmcnt(2)\n"
+                                "s_setprio 0\n" XOR8 "s_setprio 2\n" BCNT8 AND1
+                                "ds_read_b128 v[24:27], %0 offset:96\n ds_read_b128 v[28:31], %0 offset:112\n s_waitcnt lgkmcnt(2)\n"
+                                "s_setprio 0\n" XOR8 "s_setprio 2\n" BCNT8 AND1) ::"v"(addr) : CLOB);
+            if (MODE == 29)
+                asm volatile(X4("ds_read_b128 v[24:27], %0\n ds_read_b128 v[28:31], %0 offset:16\n s_waitcnt lgkmcnt(2)\n"
+                                "s_setprio 0\n" XOR8 XOR8_B "s_setprio 2\n" BCNT16_2ROWS AND1 AND1
+                                "ds_read_b128 v[24:27], %0 offset:32\n ds_read_b128 v[28:31], %0 offset:48\n s_waitcnt lgkmcnt(2)\n"
+                                "s_setprio 0\n" XOR8 XOR8_B "s_setprio 2\n" BCNT16_2ROWS AND1 AND1) ::"v"(addr) : CLOB);
+            if (MODE == 30)
+                asm volatile(X4(X4("s_setprio 0\n" XOR8 "s_setprio 2\n" BCNT8 AND1)) ::: CLOB);
+            addr = (addr + 128) & 8191;
+            it += 7;
+        }
         if (MODE == 5) {
             // the kernel's row: two wave-uniform (broadcast) 16-byte LDS reads land in the registers the next row's xors
             // consume; the wait is for the reads issued one row earlier
@@ -172,6 +196,9 @@ int main(int argc, char** argv) {
         run<25>("two rows at once x8, prio 2 on bcnts", 32, w, out, d_st, spin_s);
         run<26>("row x16, s_setprio 2 around the XORs", 32, w, out, d_st, spin_s);
         run<27>("row+and x16, prio 3 on bcnts (17/row)", 34, w, out, d_st, spin_s);
+        run<30>("row+and x16, prio 2 (17/row)", 34, w, out, d_st, spin_s);
+        run<28>("  + 2 ds_read_b128 per row (kernel, R=1)", 34, w, out, d_st, spin_s);
+        run<29>("  + 2 ds_read_b128 per TWO rows (R=2)", 34, w, out, d_st, spin_s);
         run<12>("v_bcnt x256, ONE serial chain", 32, w, out, d_st, spin_s);
         run<13>("row x16, two chains + v_add (17/row)", 34, w, out, d_st, spin_s);
         run<14>("two rows at once x8 (16 xor, 16 bcnt)", 32, w, out, d_st, spin_s);
