@@ -17,7 +17,7 @@
 // 256-thread form - a lone wave exposes the latency of every dependent f64 instruction, which costs more than the ten
 // barriers per trial it saves.  Where the time goes: the schedule makes ~70 trials (24 accepted, and every round ends
 // with ten rejected ones: g2o gives up after maxTrialsAfterFailure), a trial is one evaluation (2.4 us) plus solve,
-// exponential and bookkeeping (2.2 us).  One host core running the same loop in plain C (oracle/pose_lm_oracle.c) takes
+// exponential and bookkeeping (2.2 us).  One host core running the same loop in plain C (the test suite's CPU statement) takes
 // 102 / 372 / 576 / 2728 us at 50 / 200 / 256 / 1000 edges: at the reference's frame size (<= 200 edges, slam.py:23)
 // a single refinement gains nothing from the GPU; the batch form below (one workgroup per frame) is where it does:
 // 16 frames x 200 edges in 0.68 ms = 42 us per frame.
