@@ -124,11 +124,14 @@ SLAM_API int slam_bf_knn2_u256_host(slam_ctx* ctx, const uint8_t* h_query, int64
  *                     publish exact per-query bounds early (shipped: M/8 up to 8192 for M >= 16384, none below);
  *                     -1 = no leaders
  *   [3] lead_chunk    rows per leader chunk, a multiple of 32 (shipped: about one leader block per CU)
- *   [4] tail          number of linearly shrinking chunks at the end of the grid (shipped: 16); -1 = none */
-#define SLAM_BF_KNOBS 5
+ *   [4] tail          number of linearly shrinking chunks at the end of the grid (shipped: 16); -1 = none
+ *   [5] feed          how train rows reach the lanes at R = 1: 1 = through SGPRs (scalar loads, no LDS), -1 = through an LDS
+ *                     tile (shipped: SGPRs when a chunk has at least 512 rows, the LDS tile below that) */
+#define SLAM_BF_KNOBS 6
 SLAM_API int slam_bf_set_tuning(slam_ctx* ctx, const int32_t* h_knobs, int count);
-/* The launch plan slam_bf_knn2_u256 would use for N x M on this context: h_plan int32 [8] =
- * {R, query blocks, uniform chunk rows, chunks, leader rows, leader chunks, shrinking tail chunks, CUs}. */
+/* The launch plan slam_bf_knn2_u256 would use for N x M on this context: h_plan int32 [10] =
+ * {R, query blocks, uniform chunk rows, chunks, leader rows, leader chunks, shrinking tail chunks, CUs,
+ *  feed (1 = train rows through SGPRs, 0 = through an LDS tile), 0}. */
 SLAM_API int slam_bf_plan_info(slam_ctx* ctx, int64_t N, int64_t M, int32_t* h_plan);
 /* Restore the matcher's per-context merge state to its idle values.  Every search leaves it clean by itself;
  * call this after a search failed part-way (the library does so on a failed launch).  Stream-ordered. */

@@ -45,6 +45,7 @@
 // operands make v_xor a 4-cycle op, which is why train rows come from LDS into
 // VGPRs.
 #include "internal.h"
+#include "bf_scan_sgpr.h"
 #include <stdio.h>
 #include <vector>
 
@@ -227,7 +228,7 @@ __device__ __forceinline__ u32 merge_into_slot(unsigned long long* slot, unsigne
 // blocks pick the bound up at their next share point.  Measured and dropped: holding the other blocks back until their
 // leaders are done (-15..20 %: the leaders alone cannot keep the SIMDs busy) and raising the leaders' wave priority
 // with s_setprio (no change: as the oldest waves of their SIMDs they are served first anyway).
-template <int R>
+template <int R, bool SFEED>
 __global__ __launch_bounds__(256) void bf_top2_kernel(const uint4* __restrict__ q, int N,
                                                       const uint4* __restrict__ t, const int* __restrict__ tbl,
                                                       int lead, bf_state st, int train_base,
@@ -267,79 +268,122 @@ __global__ __launch_bounds__(256) void bf_top2_kernel(const uint4* __restrict__ 
     const int t0 = tbl[blockIdx.y];
     const int t1 = tbl[blockIdx.y + 1];
 
-    // prologue: first tile -> LDS buffer 0
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-        const int g = 2 * t0 + tid + i * 256;
-        tile[0][tid + i * 256] = g < 2 * t1 ? t[(size_t)g] : make_uint4(0, 0, 0, 0);
-    }
-    __syncthreads();
-
-    int buf = 0;
-    for (int tb = t0; tb < t1; tb += SLAM_TILE_ROWS) {
-        // issue the next tile's global loads before computing on this one
-        const int nb = tb + SLAM_TILE_ROWS;
-        uint4 nxt[2];
-        if (nb < t1) {
-#pragma unroll
-            for (int i = 0; i < 2; i++) {
-                const int g = 2 * nb + tid + i * 256;
-                nxt[i] = g < 2 * t1 ? t[(size_t)g] : make_uint4(0, 0, 0, 0);
-            }
-        }
-        share_bound<R>(bound, qbase, N, b2, init);
-        const int cnt = __builtin_amdgcn_readfirstlane(min(SLAM_TILE_ROWS, t1 - tb));
-        const uint4* tp = tile[buf];
-        // software pipeline: the next row is read from LDS while the current one is computed (the last
-        // read-ahead lands in the tile's padding and is discarded).  Measured: letting the compiler batch
-        // a whole group's reads behind immediate offsets is 6 % slower than this rolling form.
-        int j = 0;
-        uint4 a0 = tp[0], c0 = tp[1];
-        constexpr int U = SLAM_GROUP_PAIRS / R;   // 16 rows at R = 1 (59 VGPRs, still 8 waves/SIMD)
-        static_assert(U >= 2 && U % 2 == 0, "row pipeline handles rows in pairs");
-        // A block starts with no threshold of its own, so in its first tile nearly every group takes the
-        // update path; there the bound is re-read after 16, 32, 64 and 128 rows (what the sibling blocks
-        // have scanned meanwhile tightens it), later once per tile.
-        int seg_end = tb == t0 ? 16 : cnt;
-        while (true) {
-            const int lim = min(seg_end, cnt);
-            for (; j + U <= lim; j += U) {
-                u32 acc[U][R];
-                // rows are read through ONE running LDS address in a VGPR plus immediate offsets (the tile is padded by two
-                // rows so the read-ahead needs no wrap); the empty asm after every row block ties that address to the
-                // row's result, so the reads stay where they are written - rolling, one row ahead - instead of being
-                // batched by the scheduler (batched: 67 VGPRs, 7 waves/SIMD).  Against per-read scalar address arithmetic
-                // + v_mov from SGPR this saves ~1.5 VALU and ~8 SALU instructions per row: no change where the VALU is
-                // saturated (64k x 64k), 3-12 % on latency-bound sizes (4096 x 4096 30.5 -> 26.8 us).
-                u32 base = lds_addr(tp + 2 * j);
-#pragma unroll
-                for (int u = 0; u < U; u += 2) {
-                    const uint4 a1 = lds_read16(base, (2 * u + 2) * 16), c1 = lds_read16(base, (2 * u + 3) * 16);
-                    row_acc<R>(qr, a0, c0, init, acc[u]);
-                    asm volatile("" : "+v"(base) : "v"(acc[u][0]));
-                    a0 = lds_read16(base, (2 * u + 4) * 16);
-                    c0 = lds_read16(base, (2 * u + 5) * 16);
-                    row_acc<R>(qr, a1, c1, init, acc[u + 1]);
-                    asm volatile("" : "+v"(base) : "v"(acc[u + 1][0]));
-                }
-                filter_update<R, U>(acc, (u32)(tb + j), b1, b2, init);
-            }
-            if (lim >= cnt) break;
+    if constexpr (SFEED) {
+        // Train rows reach the lanes through SGPRs (SLAM_SCAN_GROUPS_ASM, bf_scan_sgpr.h): no LDS tile, no barrier, every
+        // wave scans the chunk on its own.  The bound is exchanged where the LDS form does it: at the start, after 16 /
+        // 32 / 64 / 128 rows (a block starts with no threshold of its own, so early on nearly every group takes the
+        // update path and what the sibling blocks have scanned meanwhile tightens it), then once per 256 rows.
+        // The scalar loads run only four rows ahead, which covers an L2 hit but not a miss: each wave therefore TOUCHES
+        // the 128-byte lines of the 256 rows after the stretch it is scanning with one vector load (lanes 0-15 of wave w:
+        // lines 16 w .. 16 w + 15 of those 8 KiB) - what the LDS form's tile loads do as a side effect.  Measured
+        // (profiles/r03_ab_sgpr_feed.log): 1000 x 3000 17.5 -> 13.9 us, 8192 x 8192 54.6 -> 48.9 us with the touch.
+        static_assert(!SFEED || R == 1, "the SGPR-fed scan holds one query per lane");
+        const char* tbytes = (const char*)t;
+        auto touch = [&](int first) -> u32 {
+            const long long off = (long long)first * SLAM_DESC_BYTES + (wave * 16 + lane) * 128;
+            u32 v = 0;
+            if (lane < 16 && off < (long long)t1 * SLAM_DESC_BYTES) v = *(const u32*)(tbytes + off);
+            return v;
+        };
+        u32 warm = touch(t0);
+        asm volatile("" ::"v"(warm));                  // the first stretch: wait for it, the scan starts right away
+        int row = t0;
+        while (row < t1) {
             share_bound<R>(bound, qbase, N, b2, init);
-            seg_end *= 2;
+            const int done = row - t0;
+            const int seg = done < 16 ? 16 : (done < SLAM_TILE_ROWS ? done : SLAM_TILE_ROWS);
+            const int end = min(row + seg, t1);
+            warm = (done == 0 || done >= SLAM_TILE_ROWS) ? touch(row + SLAM_TILE_ROWS) : 0u;
+            int ng = __builtin_amdgcn_readfirstlane((end - row) >> 4);
+            if (ng > 0) {
+                const uint4* tp = t + 2 * (size_t)row;
+                u32 idx = (u32)__builtin_amdgcn_readfirstlane(row);
+                row += ng << 4;
+                SLAM_SCAN_GROUPS_ASM(qr[0], tp, ng, idx, b1[0], b2[0], init[0]);
+            }
+            for (; row < end; row++) {                 // fewer than 16 rows left: only at the end of the train set
+                const uint4 x0 = t[2 * (size_t)row], y0 = t[2 * (size_t)row + 1];
+                u32 acc1[1][R];
+                row_acc<R>(qr, x0, y0, init, acc1[0]);
+                filter_update<R, 1>(acc1, (u32)row, b1, b2, init);
+            }
+            asm volatile("" ::"v"(warm));              // the touch has landed (this keeps its register until here)
         }
-        for (; j < cnt; j++) {
-            const uint4 x0 = tp[2 * j], y0 = tp[2 * j + 1];
-            u32 acc1[1][R];
-            row_acc<R>(qr, x0, y0, init, acc1[0]);
-            filter_update<R, 1>(acc1, (u32)(tb + j), b1, b2, init);
-        }
-        if (nb < t1) {
-#pragma unroll
-            for (int i = 0; i < 2; i++) tile[buf ^ 1][tid + i * 256] = nxt[i];
+    } else {
+        // prologue: first tile -> LDS buffer 0
+    #pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int g = 2 * t0 + tid + i * 256;
+            tile[0][tid + i * 256] = g < 2 * t1 ? t[(size_t)g] : make_uint4(0, 0, 0, 0);
         }
         __syncthreads();
-        buf ^= 1;
+
+        int buf = 0;
+        for (int tb = t0; tb < t1; tb += SLAM_TILE_ROWS) {
+            // issue the next tile's global loads before computing on this one
+            const int nb = tb + SLAM_TILE_ROWS;
+            uint4 nxt[2];
+            if (nb < t1) {
+    #pragma unroll
+                for (int i = 0; i < 2; i++) {
+                    const int g = 2 * nb + tid + i * 256;
+                    nxt[i] = g < 2 * t1 ? t[(size_t)g] : make_uint4(0, 0, 0, 0);
+                }
+            }
+            share_bound<R>(bound, qbase, N, b2, init);
+            const int cnt = __builtin_amdgcn_readfirstlane(min(SLAM_TILE_ROWS, t1 - tb));
+            const uint4* tp = tile[buf];
+            // software pipeline: the next row is read from LDS while the current one is computed (the last
+            // read-ahead lands in the tile's padding and is discarded).  Measured: letting the compiler batch
+            // a whole group's reads behind immediate offsets is 6 % slower than this rolling form.
+            int j = 0;
+            uint4 a0 = tp[0], c0 = tp[1];
+            constexpr int U = SLAM_GROUP_PAIRS / R;   // 16 rows at R = 1 (59 VGPRs, still 8 waves/SIMD)
+            static_assert(U >= 2 && U % 2 == 0, "row pipeline handles rows in pairs");
+            // A block starts with no threshold of its own, so in its first tile nearly every group takes the
+            // update path; there the bound is re-read after 16, 32, 64 and 128 rows (what the sibling blocks
+            // have scanned meanwhile tightens it), later once per tile.
+            int seg_end = tb == t0 ? 16 : cnt;
+            while (true) {
+                const int lim = min(seg_end, cnt);
+                for (; j + U <= lim; j += U) {
+                    u32 acc[U][R];
+                    // rows are read through ONE running LDS address in a VGPR plus immediate offsets (the tile is padded by two
+                    // rows so the read-ahead needs no wrap); the empty asm after every row block ties that address to the
+                    // row's result, so the reads stay where they are written - rolling, one row ahead - instead of being
+                    // batched by the scheduler (batched: 67 VGPRs, 7 waves/SIMD).  Against per-read scalar address arithmetic
+                    // + v_mov from SGPR this saves ~1.5 VALU and ~8 SALU instructions per row: no change where the VALU is
+                    // saturated (64k x 64k), 3-12 % on latency-bound sizes (4096 x 4096 30.5 -> 26.8 us).
+                    u32 base = lds_addr(tp + 2 * j);
+    #pragma unroll
+                    for (int u = 0; u < U; u += 2) {
+                        const uint4 a1 = lds_read16(base, (2 * u + 2) * 16), c1 = lds_read16(base, (2 * u + 3) * 16);
+                        row_acc<R>(qr, a0, c0, init, acc[u]);
+                        asm volatile("" : "+v"(base) : "v"(acc[u][0]));
+                        a0 = lds_read16(base, (2 * u + 4) * 16);
+                        c0 = lds_read16(base, (2 * u + 5) * 16);
+                        row_acc<R>(qr, a1, c1, init, acc[u + 1]);
+                        asm volatile("" : "+v"(base) : "v"(acc[u + 1][0]));
+                    }
+                    filter_update<R, U>(acc, (u32)(tb + j), b1, b2, init);
+                }
+                if (lim >= cnt) break;
+                share_bound<R>(bound, qbase, N, b2, init);
+                seg_end *= 2;
+            }
+            for (; j < cnt; j++) {
+                const uint4 x0 = tp[2 * j], y0 = tp[2 * j + 1];
+                u32 acc1[1][R];
+                row_acc<R>(qr, x0, y0, init, acc1[0]);
+                filter_update<R, 1>(acc1, (u32)(tb + j), b1, b2, init);
+            }
+            if (nb < t1) {
+    #pragma unroll
+                for (int i = 0; i < 2; i++) tile[buf ^ 1][tid + i * 256] = nxt[i];
+            }
+            __syncthreads();
+            buf ^= 1;
+        }
     }
 
     // ---- epilogue: merge, then the last arriver of this query block decodes ----------------------
@@ -442,19 +486,22 @@ struct bf_plan {
     int lead;        // leader chunks (the first `lead` entries of the table)
     int lead_rows;   // rows they cover together
     int tail;        // shrinking chunks at the end of the table
+    int sfeed;       // 1: train rows through SGPRs (bf_scan_sgpr.h), 0: through an LDS tile
 };
 
 // Tuning overrides live in the context (0 = heuristic): set through slam_bf_set_tuning, read under ctx->mu.
 extern "C" int slam_bf_set_tuning(slam_ctx* ctx, const int32_t* h_knobs, int count) {
     SLAM_REQUIRE(ctx, "slam_bf_set_tuning: null ctx");
     SLAM_REQUIRE(count >= 0 && count <= SLAM_BF_KNOBS && (h_knobs || count == 0), "bad knob array");
-    int k[SLAM_BF_KNOBS] = {0, 0, 0, 0, 0};
+    int k[SLAM_BF_KNOBS] = {0, 0, 0, 0, 0, 0};
     for (int i = 0; i < count; i++) k[i] = h_knobs[i];
     SLAM_REQUIRE(k[0] == 0 || k[0] == 1 || k[0] == 2 || k[0] == 4 || k[0] == 8, "R must be 0, 1, 2, 4 or 8");
     SLAM_REQUIRE(k[1] >= 0 && k[1] <= 64, "blocks_per_cu out of range");
     SLAM_REQUIRE(k[2] >= -1 && k[2] <= (1 << 22), "lead_rows out of range");
     SLAM_REQUIRE(k[3] >= 0 && k[3] <= (1 << 22) && k[3] % 32 == 0, "lead_chunk must be a multiple of 32 rows");
     SLAM_REQUIRE(k[4] >= -1 && k[4] <= 4096, "tail out of range");
+    SLAM_REQUIRE(k[5] >= -1 && k[5] <= 1, "feed must be 0 (heuristic), 1 (SGPRs) or -1 (LDS tile)");
+    SLAM_REQUIRE(!(k[5] == 1 && k[0] > 1), "the SGPR-fed scan holds one query per lane (R = 1)");
     std::lock_guard<std::mutex> g(ctx->mu);
     for (int i = 0; i < SLAM_BF_KNOBS; i++) ctx->bf_knob[i] = k[i];
     return SLAM_OK;
@@ -562,16 +609,24 @@ static bf_plan make_plan(slam_ctx* ctx, int64_t N, int64_t M, std::vector<int>* 
     b.back() = (int)M;
     p.tail = (int)ts.size();
     p.S = (int)b.size() - 1;
+    // Which way the train rows travel.  Through SGPRs the scan needs no LDS read (the chip holds a higher clock) but every
+    // call of the scan exposes a scalar-load latency, and a chunk's first 256 rows make five calls: measured
+    // (profiles/r03_ab_sgpr_feed.log) it wins where a block scans many rows - 64k x 64k (chunks of 2048) 1217 -> 1080-1091 us,
+    // 2^20 x 2^20 304 -> 272 ms, 32768 x 65536 623 -> 599 us - and loses where chunks are one tile: 20000 x 20000 (256 rows)
+    // 145 -> 158 us, 65536 x 4096 122 -> 129 us.  Frame-sized calls read their rows from pinned host memory, where every
+    // scalar load would be a PCIe round trip: they have chunks of at most one tile and stay on the LDS form as well.
+    p.sfeed = p.R == 1 && (k[5] == 1 || (k[5] == 0 && p.chunk >= 2 * SLAM_TILE_ROWS)) ? 1 : 0;
     return p;
 }
 
-extern "C" int slam_bf_plan_info(slam_ctx* ctx, int64_t N, int64_t M, int32_t* h_plan /*[8]*/) {
+extern "C" int slam_bf_plan_info(slam_ctx* ctx, int64_t N, int64_t M, int32_t* h_plan /*[10]*/) {
     SLAM_REQUIRE(ctx && h_plan, "slam_bf_plan_info: null argument");
     SLAM_REQUIRE(N >= 1 && M >= 1 && M <= SLAM_MAX_TRAIN_PER_PASS && N <= (1ll << 30), "bad sizes");
     std::vector<int> tbl;
     const bf_plan p = make_plan(ctx, N, M, &tbl);
     h_plan[0] = p.R; h_plan[1] = p.qblocks; h_plan[2] = p.chunk; h_plan[3] = p.S;
     h_plan[4] = p.lead_rows; h_plan[5] = p.lead; h_plan[6] = p.tail; h_plan[7] = ctx->num_cu;
+    h_plan[8] = p.sfeed; h_plan[9] = 0;
     return SLAM_OK;
 }
 
@@ -711,12 +766,18 @@ static int bf_pass(slam_ctx* ctx, const void* d_query, int64_t N, const void* d_
     const int tb = (int)train_base;
     SLAM_HIP(hipGetLastError());
     if (int rc = slam_prof_begin(ctx)) return rc;
+#define SLAM_BF_LAUNCH(R_, F_) \
+    bf_top2_kernel<R_, F_><<<grid, block, 0, ctx->stream>>>(q, (int)N, t, d_tbl, p.lead, st, tb, oi, od, (uint4*)d_keep)
     switch (p.R) {
-        case 8: bf_top2_kernel<8><<<grid, block, 0, ctx->stream>>>(q, (int)N, t, d_tbl, p.lead, st, tb, oi, od, (uint4*)d_keep); break;
-        case 4: bf_top2_kernel<4><<<grid, block, 0, ctx->stream>>>(q, (int)N, t, d_tbl, p.lead, st, tb, oi, od, (uint4*)d_keep); break;
-        case 2: bf_top2_kernel<2><<<grid, block, 0, ctx->stream>>>(q, (int)N, t, d_tbl, p.lead, st, tb, oi, od, (uint4*)d_keep); break;
-        default: bf_top2_kernel<1><<<grid, block, 0, ctx->stream>>>(q, (int)N, t, d_tbl, p.lead, st, tb, oi, od, (uint4*)d_keep); break;
+        case 8: SLAM_BF_LAUNCH(8, false); break;
+        case 4: SLAM_BF_LAUNCH(4, false); break;
+        case 2: SLAM_BF_LAUNCH(2, false); break;
+        default:
+            if (p.sfeed) SLAM_BF_LAUNCH(1, true);
+            else SLAM_BF_LAUNCH(1, false);
+            break;
     }
+#undef SLAM_BF_LAUNCH
     if (int rc = slam_prof_end(ctx)) return rc;
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

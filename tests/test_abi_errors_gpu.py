@@ -29,12 +29,14 @@ def test_status_codes_and_messages(gpu_ctx):
     assert lib.slam_bf_set_tuning(ctx.handle, knobs(3), 1) == -1                       # R not in {1, 2, 4, 8}
     assert lib.slam_bf_set_tuning(None, knobs(1), 1) == -1 and lib.slam_bf_set_tuning(ctx.handle, knobs(1, 0, -2), 3) == -1
     assert lib.slam_bf_set_tuning(ctx.handle, knobs(1, 0, 64, 48), 4) == -1            # leader chunk not a multiple of 32
-    assert lib.slam_bf_set_tuning(ctx.handle, None, 3) == -1 and lib.slam_bf_set_tuning(ctx.handle, knobs(*[0] * 6), 6) == -1
+    assert lib.slam_bf_set_tuning(ctx.handle, None, 3) == -1 and lib.slam_bf_set_tuning(ctx.handle, knobs(*[0] * 7), 7) == -1
+    assert lib.slam_bf_set_tuning(ctx.handle, knobs(2, 0, 0, 0, 0, 1), 6) == -1        # the SGPR feed holds one query per lane
+    assert lib.slam_bf_set_tuning(ctx.handle, knobs(1, 0, 0, 0, 0, 2), 6) == -1        # feed not in {-1, 0, 1}
     assert lib.slam_bf_set_tuning(ctx.handle, None, 0) == 0                            # reset to the shipped plan
-    plan = (ctypes.c_int32 * 8)()
+    plan = (ctypes.c_int32 * 10)()
     assert lib.slam_bf_plan_info(ctx.handle, 65536, 65536, plan) == 0
-    assert plan[0] == 1 and plan[1] == 256 and plan[4] % 32 == 0 and plan[3] >= 8
-    assert lib.slam_bf_plan_info(ctx.handle, 200, 200, plan) == 0 and plan[4] == 0     # frame-sized: no leaders
+    assert plan[0] == 1 and plan[1] == 256 and plan[4] % 32 == 0 and plan[3] >= 8 and plan[8] == 1   # long chunks: SGPR feed
+    assert lib.slam_bf_plan_info(ctx.handle, 200, 200, plan) == 0 and plan[4] == 0 and plan[8] == 0   # frame-sized: no leaders, LDS tile
     assert lib.slam_bf_plan_info(ctx.handle, 0, 5, plan) == -1
     assert lib.slam_bf_reset_state(ctx.handle) == 0 and lib.slam_bf_reset_state(None) == -1
     # freeing a pointer the context does not own

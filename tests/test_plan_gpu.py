@@ -1,5 +1,5 @@
-"""GPU: the launch plan of the top-2 search (leader chunks at raised priority that publish exact bounds, optional
-wait for them, shrinking chunks at the end of the grid) must not change a single bit of the result."""
+"""GPU: the launch plan of the top-2 search (leader chunks that publish exact bounds, shrinking chunks at the end of
+the grid, queries per lane, train rows through an LDS tile or through SGPRs) must not change a single bit of the result."""
 import numpy as np
 import pytest
 
@@ -35,9 +35,10 @@ def test_every_plan_shape_is_bit_identical(gpu_ctx, n, m):
         for R in (1, 2, 4, 8):
             for lead_rows, lead_chunk in ((-1, 0), (256, 0), (512, 64), (1024, 32), (0, 0)):
                 for bpc, tail in ((0, 0), (8, 5), (0, 64), (32, -1)):
-                    ctx.set_tuning(R=R, blocks_per_cu=bpc, lead_rows=lead_rows, lead_chunk=lead_chunk, tail=tail)
-                    idx, dist = _search(ctx, dq, n, dt, m, tab)
-                    assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist), (R, lead_rows, lead_chunk, bpc, tail)
+                    for feed in ((-1, 1) if R == 1 else (0,)):     # R = 1: both ways of feeding the train rows
+                        ctx.set_tuning(R=R, blocks_per_cu=bpc, lead_rows=lead_rows, lead_chunk=lead_chunk, tail=tail, feed=feed)
+                        idx, dist = _search(ctx, dq, n, dt, m, tab)
+                        assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist), (R, lead_rows, lead_chunk, bpc, tail, feed)
     finally:
         ctx.set_tuning()
         for o in (tab, dq, dt):
@@ -60,6 +61,9 @@ def test_plan_tables_and_degenerate_inputs(gpu_ctx):
         assert p["lead_rows"] == 992 and p["lead_chunks"] == 11 and p["tail_chunks"] == 9 and p["chunks"] > 20
     finally:
         ctx.set_tuning()
+    # the feed follows the chunk length: SGPRs from 512 rows per chunk up, the LDS tile below (and for frame-sized calls)
+    assert ctx.plan_info(65536, 65536)["sgpr_feed"] == 1 and ctx.plan_info(1 << 20, 1 << 20)["sgpr_feed"] == 1
+    assert ctx.plan_info(20000, 20000)["sgpr_feed"] == 0 and ctx.plan_info(200, 200)["sgpr_feed"] == 0
     n, m = 700, 20000
     rng = np.random.default_rng(3)
     q = rng.integers(0, 256, (n, 32), dtype=np.uint8)
@@ -70,14 +74,15 @@ def test_plan_tables_and_degenerate_inputs(gpu_ctx):
             t = rng.integers(0, 256, (m, 32), dtype=np.uint8)
             rows = np.arange(n) if case == "front" else m - 1 - np.arange(n)
             t[rows] = q                                         # every query has an exact copy in / behind the leader rows
+        ridx, rdist = oracle.bf_knn_c(q, t, 2, threads=8)
         for wait in (0, 1):
-            try:
-                ctx.set_tuning(lead_rows=-wait, tail=7 * wait)
-                idx, dist = slamhip.knn_match_arrays(q, t, 2, ctx=ctx)
-            finally:
-                ctx.set_tuning()
-            ridx, rdist = oracle.bf_knn_c(q, t, 2, threads=8)
-            assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist), (case, wait)
+            for feed in (-1, 1):
+                try:
+                    ctx.set_tuning(lead_rows=-wait, tail=7 * wait, feed=feed)
+                    idx, dist = slamhip.knn_match_arrays(q, t, 2, ctx=ctx)
+                finally:
+                    ctx.set_tuning()
+                assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist), (case, wait, feed)
 
 
 def test_reset_state_between_searches(gpu_ctx):

@@ -25,7 +25,7 @@ ctx = slamhip.Context(0)
 lib, h = ctx.lib, ctx.handle
 lib.slam_exp_set_trace.argtypes = [ctypes.c_void_p]
 ctx.set_tuning(blocks_per_cu=bpc, lead_rows=seed, tail=tail)
-plan = (ctypes.c_int32 * 8)()
+plan = (ctypes.c_int32 * 10)()
 lib.slam_bf_plan_info(h, n, m, plan)
 blocks = plan[1] * plan[3]
 q = slamhip.DeviceDescriptors(ctx, np.random.default_rng(228).integers(0, 256, (n, 32), dtype=np.uint8))

@@ -29,6 +29,9 @@
 #define MIN8_E32 "v_min_u32_e32 v32, v16, v26\n v_min_u32_e32 v33, v17, v27\n v_min_u32_e32 v34, v18, v24\n v_min_u32_e32 v35, v19, v25\n v_min_u32_e32 v36, v20, v30\n v_min_u32_e32 v37, v21, v31\n v_min_u32_e32 v38, v22, v28\n v_min_u32_e32 v39, v23, v29\n"
 #define MIN8_E64 "v_min_u32_e64 v32, v16, v26\n v_min_u32_e64 v33, v17, v27\n v_min_u32_e64 v34, v18, v24\n v_min_u32_e64 v35, v19, v25\n v_min_u32_e64 v36, v20, v30\n v_min_u32_e64 v37, v21, v31\n v_min_u32_e64 v38, v22, v28\n v_min_u32_e64 v39, v23, v29\n"
 #define X4(a) a a a a
+// v_xor with the train word in an SGPR (wave-uniform operand, no LDS read, one VGPR read less per instruction)
+#define XOR8_S "v_xor_b32 v32, s20, v16\n v_xor_b32 v33, s21, v17\n v_xor_b32 v34, s22, v18\n v_xor_b32 v35, s23, v19\n v_xor_b32 v36, s24, v20\n v_xor_b32 v37, s25, v21\n v_xor_b32 v38, s26, v22\n v_xor_b32 v39, s27, v23\n"
+#define SCLOB "s20","s21","s22","s23","s24","s25","s26","s27"
 // dependency probes
 #define BCNT8_SERIAL "v_bcnt_u32_b32 v40, v32, v40\n v_bcnt_u32_b32 v40, v33, v40\n v_bcnt_u32_b32 v40, v34, v40\n v_bcnt_u32_b32 v40, v35, v40\n v_bcnt_u32_b32 v40, v36, v40\n v_bcnt_u32_b32 v40, v37, v40\n v_bcnt_u32_b32 v40, v38, v40\n v_bcnt_u32_b32 v40, v39, v40\n"
 // row with two accumulator chains (even / odd words) joined by one v_add
@@ -54,7 +57,9 @@ __global__ __launch_bounds__(256) void k(uint32_t* out, stamp* st, int iters) {
     unsigned hwid;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
     const bool slot_odd = hwid & 1;
-    if (MODE == 21 && slot_odd) asm volatile("s_setprio 3");
+    asm volatile("s_mov_b32 s20, 0x12345678\n s_mov_b32 s21, 0x9abcdef0\n s_mov_b32 s22, 0x0f1e2d3c\n s_mov_b32 s23, 0x4b5a6978\n"
+                 "s_mov_b32 s24, 0x87969fa5\n s_mov_b32 s25, 0xb4c3d2e1\n s_mov_b32 s26, 0x13579bdf\n s_mov_b32 s27, 0x2468ace0" ::: SCLOB);
+    if ((MODE == 21 || MODE == 32) && slot_odd) asm volatile("s_setprio 3");
     if (MODE == 22 && !slot_odd) asm volatile("s_setprio 3");
     asm volatile("s_memtime %0\n s_memrealtime %1\n s_waitcnt lgkmcnt(0)" : "=s"(c0), "=s"(r0)::"memory");
     uint32_t addr = 0;
@@ -112,6 +117,14 @@ __global__ __launch_bounds__(256) void k(uint32_t* out, stamp* st, int iters) {
             addr = (addr + 128) & 8191;
             it += 7;
         }
+        if (MODE == 31) { asm volatile(X4(X4(XOR8_S XOR8_S)) ::: CLOB, SCLOB); it += 7; }
+        if (MODE == 32) {
+            if (slot_odd) { asm volatile(X4(X4(BCNTONLY8 BCNTONLY8)) ::: CLOB); }
+            else { asm volatile(X4(X4(XOR8_S XOR8_S)) ::: CLOB, SCLOB); }
+            it += 7;
+        }
+        if (MODE == 33) { asm volatile(X4(X4("s_setprio 0\n" XOR8_S "s_setprio 2\n" BCNT8)) ::: CLOB, SCLOB); it += 7; }
+        if (MODE == 34) { asm volatile(X4(X4("s_setprio 0\n" XOR8_S "s_setprio 2\n" BCNT8 AND1)) ::: CLOB, SCLOB); it += 7; }
         if (MODE == 5) {
             // the kernel's row: two wave-uniform (broadcast) 16-byte LDS reads land in the registers the next row's xors
             // consume; the wait is for the reads issued one row earlier
@@ -199,6 +212,10 @@ int main(int argc, char** argv) {
         run<30>("row+and x16, prio 2 (17/row)", 34, w, out, d_st, spin_s);
         run<28>("  + 2 ds_read_b128 per row (kernel, R=1)", 34, w, out, d_st, spin_s);
         run<29>("  + 2 ds_read_b128 per TWO rows (R=2)", 34, w, out, d_st, spin_s);
+        run<31>("v_xor with SGPR operand x256", 32, w, out, d_st, spin_s);
+        run<32>("slots: even xor(SGPR), odd bcnt prio 3", 32, w, out, d_st, spin_s);
+        run<33>("row x16: 8 xor(SGPR), prio 2, 8 bcnt", 32, w, out, d_st, spin_s);
+        run<34>("row+and x16: xor(SGPR), prio 2 (17/row)", 34, w, out, d_st, spin_s);
         run<12>("v_bcnt x256, ONE serial chain", 32, w, out, d_st, spin_s);
         run<13>("row x16, two chains + v_add (17/row)", 34, w, out, d_st, spin_s);
         run<14>("two rows at once x8 (16 xor, 16 bcnt)", 32, w, out, d_st, spin_s);
