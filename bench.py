@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark: descriptor pairs/sec, brute-force Hamming knn=2 at 64k x 64k.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload 64k|loop-closure]
 
 A "step" is one pass of the hot path over one batch: all 65536 query descriptors matched
 (knn=2) against 65536 train descriptors, inputs resident in HBM before the timed region.
@@ -15,6 +15,11 @@ the N rank processes itself (before anything touches a GPU).  Under the driver's
 RANK / LOCAL_RANK / WORLD_SIZE / MASTER_PORT variables are read.  Either way the rendezvous, the
 barriers and the max-over-ranks are `slamhip.launch` (a Unix socket, standard library): no torch,
 no MPI on the control or the data path; the data path is libslamhip.so + librccl.
+
+--workload loop-closure is BASELINE configs[3]: 512 keyframes x 2048 descriptors matched all-to-all (2^20 x 2^20 pairs per
+step), the query keyframes sharded over the ranks (64 per rank at 8 GPUs), the 32 MiB train collection replicated (over
+the fabric with slam_comm_broadcast when RCCL is up, by per-rank upload otherwise), the per-shard top-2 rows all-gathered
+and decoded on the device to OpenCV's multi-image form (imgIdx, trainIdx, distance).  The default workload stays 64k x 64k.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline      — the dominant kernel (bf_top2_kernel) against the HBM roofline on ALGORITHMIC
@@ -47,18 +52,17 @@ for p in (os.path.join(ROOT, "slam-experiments_amd"), ROOT):
 
 N_QUERY = 65536
 N_TRAIN = 65536
+LC_KEYFRAMES, LC_ROWS = 512, 2048   # loop closure, BASELINE configs[3]
 HBM_PEAK_GBS = 8000.0             # MI355X HBM3E spec (MI355X_MICROARCH.md)
-VALU_LANES_PER_S = 256 * 4 * 32 * 2.4e9   # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz
+VALU_LANES_PER_S = 256 * 4 * 32 * 2.4e9   # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (nominal clock: a fraction of this can never exceed 1)
 OPS_PER_PAIR = 16                 # 8 v_xor + 8 v_bcnt per 256-bit pair (algorithmic minimum, no MFMA)
-# measured issue cost (tools/ubench/valu_rate.hip): v_xor 2 cycles, v_bcnt 4 cycles per wave64
-CYCLES_PER_PAIRSTEP = 8 * 2 + 8 * 4
-ROW_LOOP_CYCLES = 54.8            # measured: isolated [lgkmcnt wait, 8 v_xor, 8 v_bcnt, 2 ds_read_b128] row loop, 2.38 GHz
-# sustained issue cost of the two instructions themselves at 8 waves/SIMD (tools/ubench/class_order.hip,
-# profiles/r02_ubench_class_order.log): v_xor_b32 2.54, v_bcnt_u32_b32 4.48 cycles per wave64
-OP_RATE_CYCLES_PER_ROW = 8 * 2.54 + 8 * 4.48
+# A gfx950 SIMD executes a wave64 VALU instruction in 4 cycles and runs two at once when they come from different waves
+# and at most one of them is a v_bcnt (measured in shader cycles, tools/ubench/cycles.hip, profiles/r03_ubench_cycles.log):
+# 16 instructions per wave-row cannot take fewer than 16 x 4 / 2 = 32 cycles per SIMD - the same bound as the 32-lane peak.
+DUAL_ISSUE_CYCLES_PER_ROW = 16 * 4 / 2
 SPIN_UP_PASSES = 24               # the GPU needs ~10 passes (~20 ms) of load before DVFS reaches its steady clock (tools/ramp.py)
-HBM_COUNTERS = os.path.join(ROOT, "profiles", "r02_hbm_counters.json")
-KERNEL_SOURCES = {"bf_top2_kernel": "bf_hamming.hip", "reproj_rj_kernel": "reproj.hip"}
+HBM_COUNTERS = os.path.join(ROOT, "profiles", "hbm_counters.json")   # tools/profile.sh refreshes it; stamped with the kernel source hashes
+KERNEL_SOURCES = {"bf_top2_kernel": ("bf_hamming.hip", "bf_scan_sgpr.h"), "reproj_rj_kernel": ("reproj.hip",)}
 
 
 def source_sha(name: str) -> str:
@@ -72,15 +76,17 @@ def profiled_traffic(kernel: str):
 
     PMC counters cannot be collected from inside this process; the separate FETCH_SIZE / WRITE_SIZE passes over this
     same command are summarised (with the gfx950 corrections) by tools/pmc_summary.py, which stamps the file with the
-    hash of the kernel source it was collected on.  A stamp that no longer matches the source means the numbers
+    hashes of the kernel sources it was collected on.  A stamp that no longer matches the sources means the numbers
     describe an older kernel: they are then withheld instead of printed."""
     try:
         with open(HBM_COUNTERS) as f:
             rec = json.load(f)
-        want, have = rec["source_sha"][KERNEL_SOURCES[kernel]], source_sha(KERNEL_SOURCES[kernel])
-        if want != have:
-            return None, f"{os.path.relpath(HBM_COUNTERS, ROOT)} was collected on {KERNEL_SOURCES[kernel]} {want}, the source is now {have}"
-        return float(rec[kernel]["traffic_bytes"]), f"{os.path.relpath(HBM_COUNTERS, ROOT)} (rocprofv3 PMC, separate passes, N=1 launch, source {have})"
+        for src in KERNEL_SOURCES[kernel]:
+            want, have = rec["source_sha"][src], source_sha(src)
+            if want != have:
+                return None, f"{os.path.relpath(HBM_COUNTERS, ROOT)} was collected on {src} {want}, the source is now {have}"
+        return float(rec[kernel]["traffic_bytes"]), (f"{os.path.relpath(HBM_COUNTERS, ROOT)} (rocprofv3 PMC, separate passes, N=1 launch, "
+                                                      f"sources {', '.join(KERNEL_SOURCES[kernel])} unchanged since)")
     except (OSError, KeyError, ValueError) as exc:
         return None, f"no usable PMC summary ({type(exc).__name__}: {exc})"
 
@@ -99,7 +105,9 @@ def cpu_baseline(query: np.ndarray, train: np.ndarray) -> dict:
     except AttributeError:
         pass
     cores = min(cores, 16)                          # the one-GPU box's CPU share
-    rows = query.shape[0]                           # the whole 65536 x 65536 workload: ~15-20 core-seconds of scalar popcnt
+    # 65536 x 65536: the whole workload (~15-20 core-seconds of popcnt per pass); loop closure: the first 65536 query rows
+    # against the whole 2^20-row collection (the same cost per query row as the full job, 1/16 of its rows)
+    rows = min(query.shape[0], max(4096, int(2 ** 36 // max(train.shape[0], 1))))
     q = query[:rows]
     oracle.bf_knn_c(q[:256], train, 2, threads=cores)   # page in / spin up the OpenMP team
     dt = float("inf")
@@ -128,7 +136,7 @@ def cpu_baseline(query: np.ndarray, train: np.ndarray) -> dict:
     return {"value": rows * train.shape[0] / dt, "unit": "pairs/s", "cores": cores, "kind": "port", "cv2": cv2_out,
             "single_thread": {"value": one_rows * train.shape[0] / dt1, "unit": "pairs/s",
                               "sample": f"first {one_rows} query rows x {train.shape[0]}, {dt1:.2f} s"},
-            "sample": f"{rows}x{train.shape[0]} (the same arrays), oracle/bf_hamming_oracle.c "
+            "sample": f"{'all' if rows == query.shape[0] else 'the first'} {rows} query rows x {train.shape[0]} train rows (the same arrays), oracle/bf_hamming_oracle.c "
                       f"(gcc -O3, {oracle.bf_simd()}, OpenMP {cores} threads), best of 3 = {dt:.2f} s wall; {cv2_leg}"}
 
 
@@ -245,6 +253,9 @@ def main() -> int:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", choices=("64k", "loop-closure"), default="64k",
+                    help="64k: 65536 x 65536 (BASELINE configs[2], the headline); loop-closure: 512 keyframes x 2048 rows "
+                         "all-to-all (BASELINE configs[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reproj", action="store_true")
     ap.add_argument("--pipelined", action="store_true",
@@ -264,12 +275,24 @@ def main() -> int:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     rz = Rendezvous(rank, world, rdzv_name or "single")
 
+    import ctypes
+
     import slamhip
     from slamhip.dist import ShardedMatcher, init_comm
 
     # SLAM_BENCH_SINGLE_DEVICE=1 (tests on a 1-GPU box): every rank uses GPU 0
     ctx = slamhip.Context(0 if os.environ.get("SLAM_BENCH_SINGLE_DEVICE") == "1" else local_rank)
-    query, train = make_descriptors(N_QUERY, 228), make_descriptors(N_TRAIN, 229)
+    loop_closure = args.workload == "loop-closure"
+    if loop_closure:
+        # every keyframe's rows are query AND train: the collection is searched with itself (each row finds itself at
+        # distance 0 first, its true nearest neighbour second - the case a loop-closure detector then has to skip)
+        n_query = n_train = LC_KEYFRAMES * LC_ROWS
+        query = train = make_descriptors(n_query, 228)
+        image_rows = [LC_ROWS] * LC_KEYFRAMES
+    else:
+        n_query, n_train = N_QUERY, N_TRAIN
+        query, train = make_descriptors(N_QUERY, 228), make_descriptors(N_TRAIN, 229)
+        image_rows = None
 
     def barrier():
         ctx.sync()
@@ -277,99 +300,138 @@ def main() -> int:
 
     collective = "none"
     rccl_ok = False
+    fallback_reason = None
+    rccl_version = ctypes.c_int(0)
+    if ctx.lib.slam_comm_version(ctypes.byref(rccl_version)) != 0:
+        rccl_version = None
     if world > 1:
         # RCCL is the data path.  If its communicator cannot be created on this node, say so loudly and use the
         # library's own direct all-gather over xGMI peer mappings (HIP IPC); if that cannot be set up either,
         # gather through the host, so that a scaling number - labelled as such - still exists.
         force = os.environ.get("SLAM_BENCH_COLLECTIVE", "")    # test hook: "p2p" / "host" skip the tiers above them
+        os.environ.setdefault("NCCL_DEBUG", "WARN")            # a failing communicator says why on stderr
         try:
             if force in ("p2p", "host"):
                 raise RuntimeError(f"skipped: SLAM_BENCH_COLLECTIVE={force}")
             init_comm(ctx, rank, world, rz.bcast)
-            failed = 0
+            failed = None
         except Exception as exc:   # noqa: BLE001 - any failure of the native init
+            failed = f"rccl: {type(exc).__name__}: {exc}"
             print(f"[bench] rank {rank}: RCCL communicator init failed ({exc}); trying peer copies over HIP IPC", file=sys.stderr)
-            failed = 1
-        rccl_ok = not max(rz.allgather(failed))                # every rank reaches this collective on every path
+        verdicts = rz.allgather(failed)                        # every rank reaches this collective on every path
+        rccl_ok = not any(verdicts)
         if not rccl_ok:
+            fallback_reason = "; ".join(f"rank {r}: {v}" for r, v in enumerate(verdicts) if v)
             ctx.lib.slam_comm_destroy(ctx.handle)
 
-    sm = ShardedMatcher(ctx, rank, world, query, train, collective="rccl" if rccl_ok else None)
+    sm = ShardedMatcher(ctx, rank, world, query, train, collective="rccl" if rccl_ok else None,
+                        broadcast_train=loop_closure, image_rows=image_rows)
+    host_gather = False
     if world > 1 and rccl_ok:
         collective = "rccl"
     elif world > 1 and os.environ.get("SLAM_BENCH_COLLECTIVE") != "host" and sm.enable_p2p(rz.allgather, barrier):
         collective = "xgmi-p2p-copies"
     elif world > 1:
         collective = "host-fallback"
-        print(f"[bench] rank {rank}: peer mapping failed too ({getattr(sm, 'p2p_error', 'marker check')}); gathering through the host", file=sys.stderr)
-        device_step = sm.step
+        why = getattr(sm, "p2p_error", "marker check failed" if os.environ.get("SLAM_BENCH_COLLECTIVE") != "host" else "skipped: SLAM_BENCH_COLLECTIVE=host")
+        fallback_reason = f"{fallback_reason}; p2p: {why}"
+        print(f"[bench] rank {rank}: peer mapping failed too ({why}); gathering through the host", file=sys.stderr)
+        host_gather = True
 
-        def host_gather_step():
-            device_step()
+    device_step = sm.step
+
+    def step():
+        device_step()
+        if host_gather:
             mine = sm.gathered[sm.last].view(rank * sm.slot_bytes, sm.slot_bytes).download(np.uint8, (sm.slot_bytes,))
-            sm.host_table = np.concatenate(rz.allgather(mine))
+            sm.gathered[sm.last].upload(np.concatenate(rz.allgather(mine)))   # every rank ends up with the full table on its device
+        if loop_closure:
+            if collective == "xgmi-p2p-copies":
+                barrier()                                      # the peers' copies into this rank's buffer have landed
+            sm.decode_images()                                 # global train row -> (imgIdx, trainIdx), on the device
 
-        sm.step = host_gather_step
-
-    # device spin-up, not part of the measurement (see SPIN_UP_PASSES)
+    # device spin-up, not part of the measurement (see SPIN_UP_PASSES; a loop-closure pass is 0.3 s of load by itself)
     ctx.prof_enable(True)              # creates the event pool now, so that no idle gap precedes the timed region
-    for _ in range(SPIN_UP_PASSES):
-        sm.step()
+    for _ in range(2 if loop_closure else SPIN_UP_PASSES):
+        step()
     barrier()
     for _ in range(args.warmup):
-        sm.step()
+        step()
     barrier()
     ctx.prof_read()                    # drop what the untimed passes recorded
     t0 = time.perf_counter()
     ctx.timer_start()
     for _ in range(args.steps):
-        sm.step()
+        step()
     dev_ms = ctx.timer_stop()          # HIP events on the stream the kernels run on; synchronises
     barrier()
     wall_ms = (time.perf_counter() - t0) * 1e3
     launches, kernel_ms_total = ctx.prof_read()
     ctx.prof_enable(False)
+    my_kernel_ms = kernel_ms_total / max(launches, 1)
 
-    times = rz.allgather((wall_ms, dev_ms))                    # MAX over ranks
+    times = rz.allgather((wall_ms, dev_ms, my_kernel_ms))      # MAX over ranks
     wall_ms, dev_ms = max(t[0] for t in times), max(t[1] for t in times)
+    rank_kernel_ms = [t[2] for t in times]
 
     # correctness of what was timed: full table on every rank, spot-checked against the oracle on rank 0
-    if collective == "host-fallback":
-        raw = sm.host_table.view(np.int32).reshape(world, 2, sm.per, 2)
-        idx = np.ascontiguousarray(raw[:, 0].reshape(world * sm.per, 2)[:N_QUERY])
-        dist_tab = np.ascontiguousarray(raw[:, 1].reshape(world * sm.per, 2)[:N_QUERY])
+    if loop_closure:
+        img, local, dist_tab = sm.result_images()
     else:
         idx, dist_tab = sm.result()
     ok = True
     if rank == 0:
         from oracle import oracle
 
-        sel = np.random.default_rng(1).choice(N_QUERY, 256, replace=False)
-        ridx, rdist = oracle.bf_knn_c(query[sel], train, 2, threads=os.cpu_count() or 1)
-        ok = bool(np.array_equal(idx[sel], ridx) and np.array_equal(dist_tab[sel], rdist))
+        sel = np.random.default_rng(1).choice(n_query, 256, replace=False)
+        if loop_closure:
+            # the oracle's multi-image search (imgIdx << 18 | trainIdx encoding, OpenCV matchers.cpp) over the 512 images
+            rimg, rlocal, rdist = oracle.bf_knn_multi_c(query[sel], [train[i * LC_ROWS:(i + 1) * LC_ROWS] for i in range(LC_KEYFRAMES)], 2,
+                                                        threads=os.cpu_count() or 1)
+            ok = bool(np.array_equal(img[sel], rimg) and np.array_equal(local[sel], rlocal) and np.array_equal(dist_tab[sel], rdist))
+            # every row is in the collection: it must find itself first, at distance 0
+            ok = ok and bool(np.array_equal(img[sel, 0], sel // LC_ROWS) and np.array_equal(local[sel, 0], sel % LC_ROWS)
+                             and not dist_tab[sel, 0].any())
+        else:
+            ridx, rdist = oracle.bf_knn_c(query[sel], train, 2, threads=os.cpu_count() or 1)
+            ok = bool(np.array_equal(idx[sel], ridx) and np.array_equal(dist_tab[sel], rdist))
 
     out = None
     if rank == 0:
         ms_per_step = wall_ms / args.steps
-        pairs = float(N_QUERY) * float(N_TRAIN)
+        pairs = float(n_query) * float(n_train)
         value = pairs / (ms_per_step * 1e-3)
-        kernel_ms = kernel_ms_total / max(launches, 1)
-        local_pairs = float(sm.n_local) * N_TRAIN                  # pairs one launch of the dominant kernel covers
-        alg_bytes = 32.0 * (sm.n_local + N_TRAIN) + 16.0 * sm.n_local   # each descriptor read once, top-2 written once
+        kernel_ms = max(rank_kernel_ms)                             # the slowest rank's shard kernel bounds the step
+        local_pairs = float(sm.n_local) * n_train                  # pairs one launch of the dominant kernel covers
+        alg_bytes = 32.0 * (sm.n_local + n_train) + 16.0 * sm.n_local   # each descriptor read once, top-2 written once
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
         lane_ops = local_pairs * OPS_PER_PAIR / (kernel_ms * 1e-3)
-        cyc_floor_ms = local_pairs / 64 * CYCLES_PER_PAIRSTEP / (256 * 4) / 2.4e9 * 1e3
-        traffic, traffic_source = profiled_traffic("bf_top2_kernel") if world == 1 else (None, "PMC passes are collected at N=1 only")
+        floor_ms = local_pairs / 64 * DUAL_ISSUE_CYCLES_PER_ROW / (256 * 4) / 2.4e9 * 1e3
+        if world == 1 and not loop_closure:
+            traffic, traffic_source = profiled_traffic("bf_top2_kernel")
+        else:
+            traffic, traffic_source = None, "PMC passes are collected on the default command only (N=1, 64k x 64k)"
+        if loop_closure:
+            metric = "descriptor pairs/sec BF-Hamming knn=2 loop-closure 512x2k all-to-all"
+            workload = (f"loop closure: {LC_KEYFRAMES} keyframes x {LC_ROWS} synthetic random 256-bit descriptors (rng seed 228) matched "
+                        f"all-to-all = 2^20 x 2^20 pairs per step, BF-Hamming knn=2 over the collection, result as "
+                        f"(imgIdx, trainIdx, distance) (BASELINE configs[3])")
+            sharding = (f"query keyframes / {world} ({LC_KEYFRAMES // world if LC_KEYFRAMES % world == 0 else 'about ' + str(LC_KEYFRAMES // world)} per rank), "
+                        f"train collection replicated ({sm.train_replication}), all-gather of top-2, decode on every rank") if world > 1 else "single GPU"
+        else:
+            metric = "descriptor pairs/sec BF-Hamming knn=2 @64kx64k"
+            workload = ("65536x65536 synthetic random 256-bit descriptors (rng seeds 228/229), "
+                        "BF-Hamming knn=2 (BASELINE configs[2])")
+            sharding = f"query rows / {world}, train replicated, all-gather of top-2" if world > 1 else "single GPU"
         out = {
-            "metric": "descriptor pairs/sec BF-Hamming knn=2 @64kx64k",
+            "metric": metric,
             "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
-            "config": {"workload": "65536x65536 synthetic random 256-bit descriptors (rng seeds 228/229), "
-                                   "BF-Hamming knn=2 (BASELINE configs[2])",
-                       "n_query": N_QUERY, "n_train": N_TRAIN,
-                       "sharding": f"query rows / {world}, train replicated, all-gather of top-2" if world > 1 else "single GPU",
-                       "collective": collective, "launch_plan": ctx.plan_info(max(sm.n_local, 1), N_TRAIN)},
+            "config": {"workload": workload, "n_query": n_query, "n_train": n_train, "sharding": sharding,
+                       "collective": collective, "collective_fallback_reason": fallback_reason,
+                       "rccl_version": None if rccl_version is None else rccl_version.value,
+                       "launch_plan": ctx.plan_info(max(sm.n_local, 1), n_train)},
             "device_ms_per_step": dev_ms / args.steps,
             "parity_spot_check": ok,
             "roofline": {
@@ -377,18 +439,17 @@ def main() -> int:
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "traffic_source": traffic_source,
                 "kernel": "bf_top2_kernel", "kernel_ms": kernel_ms, "launches": launches,
+                "kernel_ms_per_rank": {"min": min(rank_kernel_ms), "max": max(rank_kernel_ms)},
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "note": "contractual HBM figure on algorithmic bytes; the kernel is VALU-integer bound "
                         "(1.2e-3 B/pair), see valu_int",
                 "valu_int": {"lane_ops_per_pair": OPS_PER_PAIR, "achieved_lane_ops_per_s": lane_ops,
                              "peak_lane_ops_per_s": VALU_LANES_PER_S, "frac_of_32lane_peak": lane_ops / VALU_LANES_PER_S,
-                             "issue_floor_ms": cyc_floor_ms, "frac_of_issue_floor": cyc_floor_ms / kernel_ms,
-                             "issue_model": "v_xor 2 cyc + v_bcnt 4 cyc per wave64 (measured), 2.4 GHz",
-                             # tools/ubench/ring_probe.hip: the bare row loop (wait, 16 VALU, 2 ds_read_b128) at 8 waves/SIMD
-                             "sustained_op_rate_cycles_per_row": OP_RATE_CYCLES_PER_ROW,
-                             "frac_of_sustained_op_rates": (local_pairs / 64 * OP_RATE_CYCLES_PER_ROW / (256 * 4) / 2.4e9 * 1e3) / kernel_ms,
-                             "isolated_row_loop_cycles": ROW_LOOP_CYCLES,
-                             "frac_of_isolated_row_loop": (local_pairs / 64 * ROW_LOOP_CYCLES / (256 * 4) / 2.38e9 * 1e3) / kernel_ms}},
+                             "issue_floor_ms": floor_ms, "frac_of_issue_floor": floor_ms / kernel_ms,
+                             "issue_model": "16 wave64 VALU instructions per wave-row, 4 cycles each, two issue slots per SIMD "
+                                            "(one v_bcnt + one other at a time; measured in shader cycles, tools/ubench/cycles.hip), "
+                                            "at the NOMINAL 2.4 GHz: wall-clock fractions, at most 1 by construction; the in-kernel "
+                                            "clock and the cycles per wave-row at that clock are in profiles/ (tools/cycle_probe.py)"}},
         }
         if world > 1:
             out["cpu_baseline"] = None
@@ -396,9 +457,9 @@ def main() -> int:
         elif not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(query, train)
     sm.free(barrier)                   # unmap peers -> barrier -> free the exported buffers (HIP IPC teardown order)
-    if rank == 0 and world == 1 and args.pipelined:
+    if rank == 0 and world == 1 and args.pipelined and not loop_closure:
         out["pipelined"] = pipelined_leg(query, train, max(args.steps, 20))
-    if rank == 0 and world == 1 and not args.no_reproj:
+    if rank == 0 and world == 1 and not args.no_reproj and not loop_closure:
         out["reproj"] = reproj_bench(ctx, max(3, min(args.steps, 20)), args.warmup, cpu=not args.no_cpu_baseline)
     check_rc = 0
     if world > 1:

@@ -158,6 +158,16 @@ SLAM_API int slam_bf_cross_check(slam_ctx* ctx, const int32_t* d_fwd_idx, const 
                         const int32_t* d_rev_idx, int64_t M, int32_t* d_out_idx, int32_t* d_out_dist,
                         int64_t* h_count);
 
+/* Multi-image train sets (cv2.BFMatcher.add([...]) + knnMatch, the loop-closure layout; the reference constructs and
+ * queries the matcher at feature_matchers.py:34,39, the collection semantics are OpenCV's): the search runs over the
+ * concatenated rows of all images - whose order is (imgIdx, trainIdx), so ties resolve as OpenCV's do - and this turns
+ * every reported global train row back into the pair.  d_offsets int32 [images + 1]: first row of each image,
+ * ascending, d_offsets[0] = 0, d_offsets[images] = total rows; images <= 8191 and fewer than 2^18 rows per image
+ * (OpenCV's imgIdx << 18 encoding).  count entries of d_global_idx (e.g. 2 N for an [N,2] table) -> d_img_idx,
+ * d_train_idx; -1 ("no neighbour") stays -1 in both.  Asynchronous on the ctx stream. */
+SLAM_API int slam_bf_split_index(slam_ctx* ctx, const int32_t* d_global_idx, int64_t count, const int32_t* d_offsets,
+                                 int64_t images, int32_t* d_img_idx, int32_t* d_train_idx);
+
 /* ---- hot path 2: reprojection residual + Jacobians (f64) ---------------- */
 /* Per observation o with pose k = d_obs_pose[o], point l = d_obs_point[o]:
  *   p_c = R_k p_l + t_k                      (T * pos3d,  frontend.py:275)
@@ -273,6 +283,7 @@ SLAM_API int slam_ba_backsub_f64(slam_ctx* ctx, int64_t L, const int32_t* d_pt_p
 
 /* ---- multi-GPU: RCCL all-gather of per-shard result rows ---------------- */
 #define SLAM_COMM_ID_BYTES 128
+SLAM_API int slam_comm_version(int* version); /* ncclGetVersion of the librccl that was loaded (e.g. 22703); needs no GPU */
 SLAM_API int slam_comm_unique_id(void* h_id /*[128]*/);
 SLAM_API int slam_comm_init(slam_ctx* ctx, int nranks, int rank, const void* h_id);
 SLAM_API int slam_comm_destroy(slam_ctx* ctx);

@@ -193,3 +193,43 @@ extern "C" int slam_bf_cross_check(slam_ctx* ctx, const int32_t* d_fwd_idx, cons
     if (h_count) *h_count = (int64_t)h.count;
     return SLAM_OK;
 }
+
+// ---- multi-image train sets: global train row -> (imgIdx, trainIdx) ----------------------------------------------
+// cv2.BFMatcher.add([...]) + knnMatch reports, per neighbour, the image of the collection and the row inside it
+// (feature_matchers.py:34,39 construct and query the matcher; the collection semantics are OpenCV's, matchers.cpp).
+// The search runs over the concatenated rows, whose order IS (imgIdx, trainIdx), so ties resolve as OpenCV's do; this
+// turns the global row back into the pair.  offsets: int32 [images + 1], ascending, offsets[0] = 0.
+__global__ __launch_bounds__(256) void split_index_kernel(const int* __restrict__ gidx, long long n, const int* __restrict__ offsets,
+                                                          int images, int* __restrict__ img, int* __restrict__ local) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += gridDim.x * 256ll) {
+        const int g = gidx[i];
+        int im = SLAM_NO_MATCH_IDX, lo = SLAM_NO_MATCH_IDX;
+        if (g >= 0 && g < offsets[images]) {
+            int a = 0, b = images;                      // last image whose first row is <= g (empty images are skipped over)
+            while (b - a > 1) {
+                const int mid = (a + b) >> 1;
+                if (offsets[mid] <= g) a = mid; else b = mid;
+            }
+            im = a;
+            lo = g - offsets[im];
+        }
+        img[i] = im;
+        local[i] = lo;
+    }
+}
+
+extern "C" int slam_bf_split_index(slam_ctx* ctx, const int32_t* d_global_idx, int64_t count, const int32_t* d_offsets,
+                                   int64_t images, int32_t* d_img_idx, int32_t* d_train_idx) {
+    SLAM_REQUIRE(ctx, "slam_bf_split_index: null ctx");
+    SLAM_REQUIRE(count >= 0 && count <= (1ll << 32) && images >= 1 && images <= (1 << 13),
+                 "bad sizes (count=%lld, images=%lld; at most 8191 images, OpenCV's imgIdx << 18 encoding)", (long long)count, (long long)images);
+    if (count == 0) return SLAM_OK;
+    SLAM_REQUIRE(d_global_idx && d_offsets && d_img_idx && d_train_idx, "slam_bf_split_index: null device pointer");
+    SLAM_HIP(hipSetDevice(ctx->device));
+    unsigned blocks = (unsigned)((count + 255) / 256);
+    if (blocks > (unsigned)ctx->num_cu * 16) blocks = (unsigned)ctx->num_cu * 16;
+    split_index_kernel<<<dim3(blocks), dim3(256), 0, ctx->stream>>>(d_global_idx, (long long)count, d_offsets, (int)images,
+                                                                  d_img_idx, d_train_idx);
+    SLAM_HIP(hipGetLastError());
+    return SLAM_OK;
+}

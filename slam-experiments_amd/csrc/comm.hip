@@ -17,6 +17,7 @@ struct rccl_api {
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*GetVersion)(int*) = nullptr;
     bool ok = false;
 };
 rccl_api g_rccl;
@@ -40,6 +41,7 @@ int load_rccl() {
     SYM(AllGather, "ncclAllGather");
     SYM(Broadcast, "ncclBroadcast");
     SYM(GetErrorString, "ncclGetErrorString");
+    SYM(GetVersion, "ncclGetVersion");
 #undef SYM
     g_rccl.ok = true;
     return SLAM_OK;
@@ -61,6 +63,14 @@ extern "C" int slam_comm_unique_id(void* h_id) {
     ncclUniqueId id;
     SLAM_NCCL(g_rccl.GetUniqueId(&id));
     memcpy(h_id, &id, sizeof(id));
+    return SLAM_OK;
+}
+
+extern "C" int slam_comm_version(int* version) {
+    SLAM_REQUIRE(version, "slam_comm_version: null pointer");
+    *version = 0;
+    if (int rc = load_rccl()) return rc;
+    SLAM_NCCL(g_rccl.GetVersion(version));
     return SLAM_OK;
 }
 

@@ -57,6 +57,7 @@ SIGNATURES = {
                                      POINTER(c_int64), POINTER(c_int32)]),
     "slam_bf_cross_check": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
                                     POINTER(c_int64)]),
+    "slam_bf_split_index": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p]),
     "slam_reproj_rj_f64": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
                                    c_int64, c_double, c_double, c_double, c_double, c_void_p, c_void_p, c_void_p]),
     "slam_pose_normal_eq_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double,
@@ -82,6 +83,7 @@ SIGNATURES = {
                                  c_double, c_double, c_double, c_double, c_void_p]),
     "slam_ba_backsub_f64": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p]),
+    "slam_comm_version": (c_int, [POINTER(c_int)]),
     "slam_comm_unique_id": (c_int, [c_void_p]),
     "slam_comm_init": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "slam_comm_destroy": (c_int, [c_void_p]),

@@ -199,7 +199,12 @@ class ShardedMatcher(_Gathering):
     ``collective``: "rccl" (communicator made by ``init_comm``), "p2p" (peer copies over HIP IPC, enabled with
     ``enable_p2p``) or None (no gather: every rank keeps only its own slot)."""
 
-    def __init__(self, ctx: Context, rank: int, world: int, query, train, collective: Optional[str] = "rccl"):
+    def __init__(self, ctx: Context, rank: int, world: int, query, train, collective: Optional[str] = "rccl",
+                 broadcast_train: bool = False, image_rows=None):
+        """``broadcast_train``: with an RCCL communicator, only rank 0 uploads the train rows and the other ranks
+        receive them over the fabric (``slam_comm_broadcast``: 32 MiB for the 512 x 2048 loop-closure set) instead of
+        every rank pushing its own copy through PCIe.  ``image_rows``: the train set is a collection of images
+        (``BFMatcher.add``), ``image_rows[i]`` rows each; ``result_images()`` then reports (imgIdx, trainIdx, dist)."""
         self.ctx, self.rank, self.world = ctx, rank, world
         self.collective = collective if world > 1 else None
         self.peers: Optional[PeerMap] = None
@@ -209,7 +214,21 @@ class ShardedMatcher(_Gathering):
         a, b = self.plan.rows(rank)
         self.n_local = b - a
         self.d_query = DeviceDescriptors(ctx, query[a:b])
-        self.d_train = DeviceDescriptors(ctx, train)       # replicated: 2 MiB at 64k rows
+        self.train_replication = "per-rank upload"
+        if broadcast_train and self.collective == "rccl" and self.n_train:
+            self.d_train = DeviceDescriptors(ctx, train if rank == 0 else None, rows=self.n_train)
+            check(ctx.lib.slam_comm_broadcast(ctx.handle, self.d_train.buf.ptr, self.n_train * DESC_BYTES, 0))
+            self.train_replication = "rccl broadcast from rank 0"
+        else:
+            self.d_train = DeviceDescriptors(ctx, train)   # replicated: 2 MiB at 64k rows
+        self.image_rows = None
+        self._img_out = None
+        if image_rows is not None:
+            rows = [int(r) for r in image_rows]
+            if sum(rows) != self.n_train or any(r < 0 or r >= (1 << 18) for r in rows) or not 1 <= len(rows) <= 8191:
+                raise ValueError("image_rows must cover the train rows: 1..8191 images of fewer than 2^18 rows each")
+            self.image_rows = rows
+            self._offsets = ctx.upload(np.concatenate([[0], np.cumsum(rows)]).astype(np.int32))
         per = max(self.plan.rows_per_rank, 1)
         self.per = per
         # A gathered buffer has one slot per rank; a slot = that rank's idx rows [per,2] followed by its
@@ -254,11 +273,42 @@ class ShardedMatcher(_Gathering):
         dist = raw[:, 1].reshape(self.world * per, 2)[:n]
         return np.ascontiguousarray(idx), np.ascontiguousarray(dist)
 
+    def decode_images(self) -> None:
+        """Turn the global train rows of the most recent pass's gathered table into (imgIdx, trainIdx) on the device
+        (``slam_bf_split_index``; asynchronous).  With peer copies call it after the launcher's barrier."""
+        if self.image_rows is None:
+            raise ValueError("this matcher was built without image_rows")
+        ctx, per = self.ctx, self.per
+        if self._img_out is None:
+            self._img_out = (ctx.malloc(self.world * per * 8), ctx.malloc(self.world * per * 8))
+        if self.collective:
+            check(ctx.lib.slam_comm_wait_buffer(ctx.handle, self.last))   # main stream: behind the gather of this buffer
+        g = self.gathered[self.last]
+        for r in range(self.world):                                       # a slot = idx rows [per,2], then dist rows [per,2]
+            check(ctx.lib.slam_bf_split_index(ctx.handle, g.ptr + r * self.slot_bytes, per * 2, self._offsets.ptr,
+                                              len(self.image_rows), self._img_out[0].ptr + r * per * 8,
+                                              self._img_out[1].ptr + r * per * 8))
+
+    def result_images(self) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """(imgIdx, trainIdx, dist) int32 [N,2] of the most recent pass, in OpenCV's multi-image form."""
+        n, per = self.plan.n_query, self.per
+        self.decode_images()
+        _, dist = self.result()
+        img = self._img_out[0].download(np.int32, (self.world * per, 2))[:n]
+        local = self._img_out[1].download(np.int32, (self.world * per, 2))[:n]
+        return np.ascontiguousarray(img), np.ascontiguousarray(local), dist
+
     def free(self, barrier: Optional[Callable[[], None]] = None) -> None:
         """``barrier`` is required when the peer-copy tier is active (see ``_release``)."""
         self._release(barrier, self.gathered)
         self.d_query.free()
         self.d_train.free()
+        if self.image_rows is not None:
+            self._offsets.free()
+        if self._img_out is not None:
+            for b in self._img_out:
+                b.free()
+            self._img_out = None
 
 
 class TrainShardedMatcher(_Gathering):

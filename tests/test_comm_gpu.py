@@ -81,6 +81,46 @@ def test_self_contained_launch_two_ranks_on_one_gpu(built, force, expect):
     assert rec["cpu_baseline"] is None and "N=1" in rec["cpu_baseline_note"]
 
 
+def test_n_gt_1_line_says_which_collective_ran_and_why(built):
+    """the N > 1 line must be readable from the record alone - which tier carried the gather and why
+    the tiers above it did not (the exception text of the RCCL / peer-mapping set-up), the RCCL version, the shard
+    kernel's roofline and the per-rank kernel times."""
+    env = dict(os.environ, SLAM_BENCH_SINGLE_DEVICE="1", SLAM_BENCH_COLLECTIVE="host")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SLAM_RDZV"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"]
+    rec = _bench_line(subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT))
+    cfg, roof = rec["config"], rec["roofline"]
+    assert cfg["collective"] == "host-fallback" and "SLAM_BENCH_COLLECTIVE=host" in cfg["collective_fallback_reason"]
+    assert isinstance(cfg["rccl_version"], int) and cfg["rccl_version"] > 20000
+    assert roof["kernel"] == "bf_top2_kernel" and roof["achieved"] > 0 and 0 < roof["frac"] < 1
+    assert roof["algorithmic_bytes_per_launch"] == 32 * (32768 + 65536) + 16 * 32768          # the SHARD's bytes
+    assert 0 < roof["kernel_ms_per_rank"]["min"] <= roof["kernel_ms_per_rank"]["max"] == roof["kernel_ms"]
+    assert 0 < roof["valu_int"]["frac_of_32lane_peak"] <= 1 and 0 < roof["valu_int"]["frac_of_issue_floor"] <= 1
+    assert cfg["launch_plan"]["qblocks"] == 128
+
+
+@pytest.mark.parametrize("ranks,force", [(1, ""), (3, "p2p")])
+def test_loop_closure_workload(built, ranks, force):
+    """BASELINE configs[3] end to end: `bench.py --workload loop-closure` - 512 keyframes x 2048 rows all-to-all, query
+    keyframes sharded over the ranks, top-2 rows gathered (three processes on the one GPU: the peer-copy tier, a real
+    device-to-device gather between processes) and decoded on the device to (imgIdx, trainIdx, distance); the spot check
+    is the oracle's multi-image search (imgIdx << 18 | trainIdx, OpenCV matchers.cpp) on 256 sampled queries."""
+    env = dict(os.environ, SLAM_BENCH_SINGLE_DEVICE="1", SLAM_BENCH_COLLECTIVE=force)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SLAM_RDZV"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--workload", "loop-closure", "--steps", "2",
+           "--warmup", "0", "--no-cpu-baseline"]
+    rec = _bench_line(subprocess.run(cmd, capture_output=True, text=True, timeout=1100, env=env, cwd=ROOT))
+    assert rec["n_gpus"] == ranks and rec["parity_spot_check"] is True
+    assert rec["config"]["n_query"] == rec["config"]["n_train"] == 512 * 2048 and "loop closure" in rec["config"]["workload"]
+    assert rec["config"]["collective"] == ("none" if ranks == 1 else "xgmi-p2p-copies")
+    assert rec["roofline"]["kernel"] == "bf_top2_kernel" and rec["roofline"]["achieved"] > 0
+    assert rec["config"]["launch_plan"]["sgpr_feed"] == 1
+    if ranks == 1:
+        assert rec["value"] > 2.5e12          # round 2 measured 2.91e12 pairs/s here
+
+
 def test_driver_launch_line_two_ranks_needs_no_torch_in_the_ranks(built):
     """The driver's N > 1 line (`python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2`): the ranks read
     RANK / WORLD_SIZE / MASTER_PORT from the environment and rendezvous through slamhip.launch; torch stays the

@@ -214,6 +214,36 @@ def test_loop_closure_all_to_all_1m(gpu_ctx):
     dall.free()
 
 
+def test_split_index_on_the_device_equals_the_host_statement(gpu_ctx):
+    """slam_bf_split_index: global train row -> (imgIdx, trainIdx) for ragged collections with empty images, "no
+    neighbour" entries and indices past the end; equal to slamhip.split_image_index and to OpenCV's imgIdx << 18 form."""
+    import slamhip
+
+    ctx, lib = gpu_ctx, gpu_ctx.lib
+    rng = np.random.default_rng(11)
+    for rows in ([2048] * 512, [5, 0, 0, 17, 1, 0, 300, 2], [1], [0, 0, 9]):
+        off = np.concatenate([[0], np.cumsum(rows)]).astype(np.int32)
+        total = int(off[-1])
+        g = rng.integers(0, total, 5000).astype(np.int32)
+        g[::97] = -1
+        g[:len(off) - 1] = off[:-1].clip(0, total - 1)          # first rows of the images (an empty image shares its row with the next)
+        g[-1] = total - 1
+        d_g, d_off = ctx.upload(g), ctx.upload(off)
+        d_img, d_loc = ctx.malloc(g.size * 4), ctx.malloc(g.size * 4)
+        assert lib.slam_bf_split_index(ctx.handle, d_g.ptr, g.size, d_off.ptr, len(rows), d_img.ptr, d_loc.ptr) == 0
+        img, loc = d_img.download(np.int32, g.shape), d_loc.download(np.int32, g.shape)
+        himg, hloc = slamhip.split_image_index(g, rows)
+        assert np.array_equal(img, himg) and np.array_equal(loc, hloc), rows
+        ok = g >= 0
+        assert (off[img[ok]] + loc[ok] == g[ok]).all() and (loc[ok] < np.asarray(rows)[img[ok]]).all()
+        assert (img[~ok] == -1).all() and (loc[~ok] == -1).all()
+        for b in (d_g, d_off, d_img, d_loc):
+            b.free()
+    assert lib.slam_bf_split_index(ctx.handle, None, 5, None, 1, None, None) == -1
+    assert lib.slam_bf_split_index(ctx.handle, None, 0, None, 1, None, None) == 0
+    assert lib.slam_bf_split_index(ctx.handle, None, 5, None, 9000, None, None) == -1     # more images than imgIdx << 18 allows
+
+
 def test_resident_matcher_matches_frame_to_frame(gpu_ctx):
     """Descriptors stay on the device between frames; results equal the stateless path (and the oracle)."""
     import slamhip
