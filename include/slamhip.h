@@ -104,6 +104,25 @@ SLAM_API int slam_bf_knn2_u256(slam_ctx* ctx, const void* d_query, int64_t N,
                       const void* d_train, int64_t M, int64_t train_base,
                       int32_t* d_idx, int32_t* d_dist);
 
+/* Several INDEPENDENT searches in ONE launch: search i is slam_bf_knn2_u256(d_query, N, d_train, M, train_base, d_idx,
+ * d_dist) of the i-th entry, bit for bit.  Frame-sized searches (the reference matches <= 200 x 200 per frame,
+ * frontend.py:181-187; BASELINE configs[1] is 4096 x 4096) are bound by launch and drain latency on a half-empty chip,
+ * not by their scan: crossCheck's forward and reverse search, or a handful of candidate verifications, fill one grid
+ * instead of queueing cold ones.  At most SLAM_BF_BATCH_MAX searches per call, each over at most 2^23 train rows;
+ * h_searches is a HOST array (the descriptors travel in the kernel arguments; nothing is uploaded).  N == 0 entries are
+ * skipped, M == 0 entries report "no neighbour".  Asynchronous on the ctx stream. */
+#define SLAM_BF_BATCH_MAX 32
+typedef struct slam_bf_search {
+    const void* d_query;
+    int64_t N;
+    const void* d_train;
+    int64_t M;
+    int64_t train_base;
+    int32_t* d_idx;
+    int32_t* d_dist;
+} slam_bf_search;
+SLAM_API int slam_bf_knn2_batch_u256(slam_ctx* ctx, int64_t B, const slam_bf_search* h_searches);
+
 /* Merge G partial top-2 tables ([G][N][2] idx and dist, already holding
  * global indices) into one, by (dist, idx) order.  Used by train-sharded
  * runs and by passes over train sets larger than 2^23 rows. */

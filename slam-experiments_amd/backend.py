@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import importlib.util
 import os
+import re
 import sys
 from typing import Optional
 
@@ -28,26 +29,54 @@ from slamhip.device import Context, default_context
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
+# What identifies the reference's backend.py (backend.py:10-12, :31): the Map container with its two tuning constants.
+_REFERENCE_MARKS = ("Map", "NUM_ACTIVE_KEYFRAMES", "MIN_DIST_THRESHOLD")
+
+
 def _load_reference_backend():
-    """Find a `backend.py` on sys.path other than this one (the reference's) and load it."""
+    """Find the REFERENCE's ``backend.py`` on sys.path and load it; returns (module, report).
+
+    An overlay install puts this directory ahead of the reference's on ``sys.path`` and both files are called
+    ``backend.py``.  A candidate is accepted only if its text defines the reference's ``Map`` class together with
+    ``NUM_ACTIVE_KEYFRAMES`` and ``MIN_DIST_THRESHOLD`` (``backend.py:10-12``) - checked on the source BEFORE anything
+    is executed, so an unrelated ``backend.py`` that happens to be on the path is neither imported nor mistaken for it.
+    The current working directory (the ``''`` entry) is considered only through that same test.  ``report`` lists what
+    was looked at, for the error message."""
+    seen, report = set(), []
     for entry in sys.path:
         base = os.path.abspath(entry or os.getcwd())
-        if base == _HERE:
+        if base == _HERE or base in seen:
             continue
+        seen.add(base)
         cand = os.path.join(base, "backend.py")
-        if os.path.isfile(cand):
-            spec = importlib.util.spec_from_file_location("_reference_backend", cand)
-            mod = importlib.util.module_from_spec(spec)
-            spec.loader.exec_module(mod)
-            return mod
-    return None
+        if not os.path.isfile(cand):
+            continue
+        try:
+            with open(cand, encoding="utf-8", errors="replace") as f:
+                text = f.read()
+        except OSError as exc:
+            report.append(f"{cand}: unreadable ({exc})")
+            continue
+        missing = [m for m in _REFERENCE_MARKS if not re.search(rf"^\s*(class\s+{m}\b|{m}\s*=)", text, re.M)]
+        if missing:
+            report.append(f"{cand}: not the reference's backend.py (no {', '.join(missing)})")
+            continue
+        spec = importlib.util.spec_from_file_location("_reference_backend", cand)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        if all(hasattr(mod, m) for m in _REFERENCE_MARKS) and isinstance(mod.Map, type):
+            return mod, report
+        report.append(f"{cand}: defines the names but not as a class and two constants")
+    return None, report
 
 
 def __getattr__(name: str):
     if name == "Map":  # resolved lazily so the module imports without the reference present
-        ref = _load_reference_backend()
-        if ref is None or not hasattr(ref, "Map"):
-            raise ImportError("Map lives in the reference's backend.py, which is not on sys.path")
+        ref, report = _load_reference_backend()
+        if ref is None:
+            looked = "; ".join(report) if report else "no other backend.py on sys.path"
+            raise ImportError("Map lives in the reference's backend.py (class Map + NUM_ACTIVE_KEYFRAMES + "
+                              f"MIN_DIST_THRESHOLD), which was not found on sys.path: {looked}")
         globals()["Map"] = ref.Map
         return ref.Map
     raise AttributeError(f"module 'backend' has no attribute {name!r}")

@@ -228,19 +228,20 @@ __device__ __forceinline__ u32 merge_into_slot(unsigned long long* slot, unsigne
 // blocks pick the bound up at their next share point.  Measured and dropped: holding the other blocks back until their
 // leaders are done (-15..20 %: the leaders alone cannot keep the SIMDs busy) and raising the leaders' wave priority
 // with s_setprio (no change: as the oldest waves of their SIMDs they are served first anyway).
+// (bx, by) = the block's place in its search's grid of qblocks x S blocks: blockIdx of a single search, decoded from the
+// linear block index of a batch launch (bf_top2_batch_kernel).
 template <int R, bool SFEED>
-__global__ __launch_bounds__(256) void bf_top2_kernel(const uint4* __restrict__ q, int N,
-                                                      const uint4* __restrict__ t, const int* __restrict__ tbl,
-                                                      int lead, bf_state st, int train_base,
-                                                      int2* __restrict__ out_idx, int2* __restrict__ out_dist,
-                                                      uint4* __restrict__ keep) {
+__device__ __forceinline__ void bf_top2_block(const uint4* __restrict__ q, int N, const uint4* __restrict__ t,
+                                              const int* __restrict__ tbl, int lead, bf_state st, int train_base,
+                                              int2* __restrict__ out_idx, int2* __restrict__ out_dist,
+                                              uint4* __restrict__ keep, const int bx, const int by, const int S) {
     __shared__ uint4 tile[2][SLAM_TILE_ROWS * 2 + 4];
     __shared__ u32 s_last;
     u32* __restrict__ bound = st.bound;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int qbase = blockIdx.x * (256 * R) + wave * (64 * R) + lane;
-    const bool leader = (int)blockIdx.y < lead;
+    const int qbase = bx * (256 * R) + wave * (64 * R) + lane;
+    const bool leader = by < lead;
 
     u32 qr[R][8];
 #pragma unroll
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(256) void bf_top2_kernel(const uint4* __restrict__ 
         int qi = qbase + r * 64;
         qi = qi < N ? qi : N - 1;  // clamp: tail lanes compute a duplicate and never store
         const uint4 a = q[2 * (size_t)qi], b = q[2 * (size_t)qi + 1];
-        if (keep && blockIdx.y == 0 && qbase + r * 64 < N) {
+        if (keep && by == 0 && qbase + r * 64 < N) {
             // the caller wants the query rows left in device memory (they are the next frame's train side,
             // frontend.py:181-187): the first chunk's blocks have them in registers anyway
             keep[2 * (size_t)qi] = a;
@@ -265,8 +266,8 @@ __global__ __launch_bounds__(256) void bf_top2_kernel(const uint4* __restrict__ 
         init[r] = SLAM_ACC_BIAS - (SLAM_KEY_NONE >> SLAM_KEY_IDX_BITS);  // "distance 511": everything enters
     }
 
-    const int t0 = tbl[blockIdx.y];
-    const int t1 = tbl[blockIdx.y + 1];
+    const int t0 = tbl[by];
+    const int t1 = tbl[by + 1];
 
     if constexpr (SFEED) {
         // Train rows reach the lanes through SGPRs (SLAM_SCAN_GROUPS_ASM, bf_scan_sgpr.h): no LDS tile, no barrier, every
@@ -412,9 +413,9 @@ __global__ __launch_bounds__(256) void bf_top2_kernel(const uint4* __restrict__ 
     if (tid == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const u32 ticket = __hip_atomic_fetch_add(&st.arrivals[blockIdx.x], 1u, __ATOMIC_RELAXED,
+        const u32 ticket = __hip_atomic_fetch_add(&st.arrivals[bx], 1u, __ATOMIC_RELAXED,
                                                   __HIP_MEMORY_SCOPE_AGENT);
-        s_last = ticket == gridDim.y - 1 ? 1u : 0u;
+        s_last = ticket == (u32)S - 1 ? 1u : 0u;
         if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -439,7 +440,43 @@ __global__ __launch_bounds__(256) void bf_top2_kernel(const uint4* __restrict__ 
             __hip_atomic_store(&st.bound[qi], 0x7F7F7F7Fu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    if (tid == 0) __hip_atomic_store(&st.arrivals[blockIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) __hip_atomic_store(&st.arrivals[bx], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int R, bool SFEED>
+__global__ __launch_bounds__(256) void bf_top2_kernel(const uint4* __restrict__ q, int N,
+                                                      const uint4* __restrict__ t, const int* __restrict__ tbl,
+                                                      int lead, bf_state st, int train_base,
+                                                      int2* __restrict__ out_idx, int2* __restrict__ out_dist,
+                                                      uint4* __restrict__ keep) {
+    bf_top2_block<R, SFEED>(q, N, t, tbl, lead, st, train_base, out_idx, out_dist, keep, (int)blockIdx.x, (int)blockIdx.y,
+                            (int)gridDim.y);
+}
+
+// ---- several independent searches in ONE launch -------------------------------------------------------------------
+// A frame-sized search is a cold, half-empty grid: launch + drain latency, not the scan, is what it costs (4096 x 4096:
+// 27 us for 17 M pairs).  crossCheck needs two such searches (query -> train and train -> query), candidate
+// verification a handful: instead of queueing cold grids behind one another, the searches share one grid.  The
+// descriptors travel BY VALUE in the kernel argument segment (no upload in front of the launch); a block finds its
+// search by walking the prefix sums of the searches' block counts (wave-uniform, a few scalar compares).
+struct bf_search {
+    const uint4* q; const uint4* t; const int* tbl; int2* out_idx; int2* out_dist; uint4* keep;
+    bf_state st;
+    int N, lead, S, qblocks, train_base, first_block;
+};
+struct bf_batch {
+    int count, pad;
+    bf_search s[SLAM_BF_BATCH_MAX];
+};
+
+__global__ __launch_bounds__(256) void bf_top2_batch_kernel(const bf_batch b) {
+    int i = 0;
+    const int id = (int)blockIdx.x;
+    while (i + 1 < b.count && id >= b.s[i + 1].first_block) i++;
+    const bf_search& p = b.s[i];
+    const int local = id - p.first_block;           // x fastest, as in the single search: consecutive blocks = consecutive query blocks
+    bf_top2_block<1, false>(p.q, p.N, p.t, p.tbl, p.lead, p.st, p.train_base, p.out_idx, p.out_dist, p.keep, local % p.qblocks,
+                            local / p.qblocks, p.S);
 }
 
 // merge G decoded tables by (dist, idx)
@@ -507,29 +544,36 @@ extern "C" int slam_bf_set_tuning(slam_ctx* ctx, const int32_t* h_knobs, int cou
     return SLAM_OK;
 }
 
-// uniform chunks of the rows [0, M) for a given R: aim at `blocks_per_cu` blocks per CU, a chunk being at least one LDS tile
-static void plan_uniform(const slam_ctx* ctx, int64_t N, int64_t M, int R, int blocks_per_cu, bool forced, bf_plan* p) {
+// uniform chunks of the rows [0, M) for a given R: aim at `blocks_per_cu` blocks per CU, a chunk being at least one LDS tile.
+// qb_all: the query blocks of ALL searches that share the launch (a batch), or 0 for a search that has the grid to itself.
+static void plan_uniform(const slam_ctx* ctx, int64_t N, int64_t M, int R, int blocks_per_cu, bool forced, int64_t qb_all,
+                         bf_plan* p) {
     const int64_t tiles = (M + SLAM_TILE_ROWS - 1) / SLAM_TILE_ROWS;
     p->R = R;
     p->qblocks = (int)((N + 256 * R - 1) / (256 * R));
+    if (qb_all < p->qblocks) qb_all = p->qblocks;
     // 32 blocks per CU = 4 rounds at 8 waves/SIMD: finished waves keep being replaced, so the
     // under-occupied tail (a lone wave per SIMD issues at under half rate) is short; query shards
     // with fewer query blocks than CUs (multi-GPU runs) measured 3-5 % faster still with 64.
     if (!blocks_per_cu) blocks_per_cu = p->qblocks >= ctx->num_cu ? 32 : 64;
-    int64_t S = (int64_t)ctx->num_cu * blocks_per_cu / p->qblocks;
+    int64_t S = (int64_t)ctx->num_cu * blocks_per_cu / qb_all;
     if (S > tiles) S = tiles;
     if (S < 1) S = 1;
     int64_t chunk = (M + S - 1) / S;
     chunk = (chunk + SLAM_TILE_ROWS - 1) / SLAM_TILE_ROWS * SLAM_TILE_ROWS;
-    // Frame-sized problems (fewer 256-row blocks than CUs; the reference matches <= 200 x 200, slam.py:23) are
-    // latency-bound on one block's serial scan: cut the train rows into sub-tile chunks, one block per CU.
-    // Measured: 200 x 200 21.6 -> 9.1 us, 1000 x 1000 27.1 -> 12.7 us, 2000 x 2000 28.5 -> 19.5 us; from
-    // 4096 x 4096 up finer chunks only add cold starts and merges (34 -> 46-91 us), so those keep whole tiles.
-    if (!forced && (int64_t)p->qblocks * tiles < ctx->num_cu) {
-        int64_t want = ctx->num_cu / p->qblocks;
-        int64_t c2 = (M + want - 1) / want;
+    if (!forced && M < 16384) {
+        // Train sets below the leader regime.  Every block starts cold (nearly every group of its first rows takes the
+        // update path), so a chunk costs its rows PLUS a fixed start-up, and a small launch costs launch + drain latency
+        // on a grid that may not fill the chip.  Measured over single searches from 200 x 200 to 12000 x 12000 and over
+        // batches of 2-32 searches (tools/batch_sweep.py, profiles/r03_batch_chunk_sweep.log): the best chunk gives
+        // every CU about ONE block - as few cold starts as the chip can be filled with - but is never longer than 512
+        // rows (beyond that the grid drains badly) nor shorter than 32.  Frame-sized searches (the reference matches
+        // <= 200 x 200, slam.py:23) come out at 32-64 rows per block (200 x 200 21.6 -> 9.1 us when this was
+        // introduced), 4096 x 4096 at 256, everything from 6000 x 6000 and every well-filled batch at 512:
+        // 12000 x 12000 74 -> 62 us, 65536 x 4096 122 -> 101 us, sixteen 4096 x 4096 in one launch 186 -> 126 us.
+        int64_t c2 = (M * qb_all + ctx->num_cu - 1) / ctx->num_cu;
         c2 = (c2 + 31) / 32 * 32;
-        if (c2 < chunk) chunk = c2;
+        chunk = c2 < 32 ? 32 : (c2 > 512 ? 512 : c2);
     }
     p->chunk = (int)chunk;
 }
@@ -542,13 +586,13 @@ static void plan_uniform(const slam_ctx* ctx, int64_t N, int64_t M, int R, int b
 //   uniform:  chunks of p.chunk rows.
 //   tail:     the last `tail` chunks shrink linearly, so the blocks dispatched last (the youngest waves, which the
 //             age-ordered VALU arbiter serves last) have the least left to do when the grid drains.
-static bf_plan make_plan(slam_ctx* ctx, int64_t N, int64_t M, std::vector<int>* tbl) {
+static bf_plan make_plan(slam_ctx* ctx, int64_t N, int64_t M, std::vector<int>* tbl, int64_t qb_all = 0) {
     std::lock_guard<std::mutex> g(ctx->mu);
     const int* k = ctx->bf_knob;
     bf_plan p;
     // R = 1 query per lane measured fastest at every size tried (64k x 64k: 1.68 ms vs 1.79 ms for R = 2,
     // 1.96 ms for R = 4; 58 VGPRs, 8 waves/SIMD); R = 2 / 4 / 8 stay available through slam_bf_set_tuning.
-    plan_uniform(ctx, N, M, k[0] ? k[0] : 1, k[1], k[1] != 0, &p);
+    plan_uniform(ctx, N, M, k[0] ? k[0] : 1, k[1], k[1] != 0, qb_all, &p);
     const int64_t slots = (int64_t)ctx->num_cu * 8;                      // resident blocks of 4 waves at 8 waves/SIMD
     // ---- leaders
     int64_t lead_rows = k[2] < 0 ? 0 : k[2];
@@ -828,6 +872,80 @@ int slam_bf_knn2_keep(slam_ctx* ctx, const void* d_query, int64_t N, const void*
             return rc;
     }
     return slam_bf_merge_top2(ctx, idx_parts, dist_parts, passes, N, d_idx, d_dist);
+}
+
+// B independent searches in one launch (see bf_top2_batch_kernel).  h_keep: per search, where to leave a device copy of
+// its query rows (or null); may itself be null.
+int slam_bf_knn2_batch_keep(slam_ctx* ctx, int64_t B, const slam_bf_search* h_searches, void* const* h_keep) {
+    SLAM_REQUIRE(ctx, "slam_bf_knn2_batch_u256: null ctx");
+    SLAM_REQUIRE(B >= 0 && B <= SLAM_BF_BATCH_MAX, "B=%lld searches, at most %d per call", (long long)B, SLAM_BF_BATCH_MAX);
+    if (B == 0) return SLAM_OK;
+    SLAM_REQUIRE(h_searches, "slam_bf_knn2_batch_u256: null search table");
+    int64_t rows = 0, qb_all = 0;
+    for (int64_t i = 0; i < B; i++) {
+        const slam_bf_search& h = h_searches[i];
+        SLAM_REQUIRE(h.N >= 0 && h.M >= 0 && h.N <= (1ll << 30), "search %lld: bad sizes (N=%lld, M=%lld)", (long long)i, (long long)h.N, (long long)h.M);
+        SLAM_REQUIRE(h.M <= SLAM_MAX_TRAIN_PER_PASS, "search %lld: a batched search covers at most 2^23 train rows", (long long)i);
+        SLAM_REQUIRE(h.train_base >= 0 && h.train_base + h.M <= 0x7FFFFFFFll, "search %lld: train_base + M must fit int32", (long long)i);
+        if (h.N == 0) continue;
+        SLAM_REQUIRE(h.d_query && h.d_idx && h.d_dist && (h.d_train || h.M == 0), "search %lld: null device pointer", (long long)i);
+        SLAM_REQUIRE(((uintptr_t)h.d_query & 15) == 0 && ((uintptr_t)h.d_train & 15) == 0 &&
+                     (!h_keep || ((uintptr_t)h_keep[i] & 15) == 0), "search %lld: descriptor pointers must be 16-byte aligned", (long long)i);
+        rows += (h.N + 255) / 256 * 256;            // every search's state starts on a query-block boundary
+        if (h.M) qb_all += (h.N + 255) / 256;
+    }
+    SLAM_HIP(hipSetDevice(ctx->device));
+    bf_batch batch;
+    memset(&batch, 0, sizeof(batch));
+    std::vector<int> tables;
+    std::vector<size_t> tbl_at;
+    int64_t row0 = 0;
+    int blocks = 0;
+    bf_state st;
+    if (rows)
+        if (int rc = bf_state_get(ctx, rows, &st)) return rc;
+    for (int64_t i = 0; i < B; i++) {
+        const slam_bf_search& h = h_searches[i];
+        if (h.N == 0) continue;
+        if (h.M == 0) {                                 // no train rows: every query reports "no neighbour"
+            bf_fill_none_kernel<<<dim3((unsigned)((h.N + 255) / 256)), dim3(256), 0, ctx->stream>>>((int)h.N, (int2*)h.d_idx,
+                                                                                                 (int2*)h.d_dist);
+            SLAM_HIP(hipGetLastError());
+            continue;
+        }
+        std::vector<int> tbl;
+        const bf_plan p = make_plan(ctx, h.N, h.M, &tbl, qb_all);
+        SLAM_REQUIRE(p.R == 1, "slam_bf_knn2_batch_u256 runs at one query per lane: clear the R override (slam_bf_set_tuning)");
+        bf_search& d = batch.s[batch.count++];
+        d.q = (const uint4*)h.d_query; d.t = (const uint4*)h.d_train;
+        d.out_idx = (int2*)h.d_idx; d.out_dist = (int2*)h.d_dist;
+        d.keep = h_keep ? (uint4*)h_keep[i] : nullptr;
+        d.st.best = st.best + row0; d.st.bound = st.bound + row0; d.st.arrivals = st.arrivals + row0 / 256;
+        d.N = (int)h.N; d.lead = p.lead; d.S = p.S; d.qblocks = p.qblocks; d.train_base = (int)h.train_base;
+        d.first_block = blocks;
+        tbl_at.push_back(tables.size());
+        tables.insert(tables.end(), tbl.begin(), tbl.end());
+        blocks += p.qblocks * p.S;
+        row0 += (h.N + 255) / 256 * 256;
+    }
+    if (batch.count == 0) return SLAM_OK;
+    const int* d_tbl = nullptr;
+    if (int rc = bf_table_get(ctx, tables, &d_tbl)) return rc;
+    for (int i = 0; i < batch.count; i++) batch.s[i].tbl = d_tbl + tbl_at[i];
+    SLAM_HIP(hipGetLastError());
+    if (int rc = slam_prof_begin(ctx)) return rc;
+    bf_top2_batch_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(batch);
+    if (int rc = slam_prof_end(ctx)) return rc;
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        (void)slam_bf_reset_state(ctx);
+        return slam_set_error(SLAM_ERR_HIP, "batched top-2 kernel launch failed: %s", hipGetErrorString(e));
+    }
+    return SLAM_OK;
+}
+
+extern "C" int slam_bf_knn2_batch_u256(slam_ctx* ctx, int64_t B, const slam_bf_search* h_searches) {
+    return slam_bf_knn2_batch_keep(ctx, B, h_searches, nullptr);
 }
 
 extern "C" int slam_bf_merge_top2(slam_ctx* ctx, const int32_t* d_idx_parts, const int32_t* d_dist_parts,

@@ -75,6 +75,8 @@ int slam_io_arena(slam_ctx* ctx, uint64_t dev_bytes, uint64_t host_bytes, void**
 // for the copy to happen: with no train rows no kernel reads the queries)
 int slam_bf_knn2_keep(slam_ctx* ctx, const void* d_query, int64_t N, const void* d_train, int64_t M, int64_t train_base,
                       int32_t* d_idx, int32_t* d_dist, void* d_keep);
+// slam_bf_knn2_batch_u256 with optional per-search copies of the query rows (h_keep[i] or null; h_keep may be null)
+int slam_bf_knn2_batch_keep(slam_ctx* ctx, int64_t B, const slam_bf_search* h_searches, void* const* h_keep);
 // the filter kernels of slam_bf_match_filter without the read-back (asynchronous on the ctx stream)
 int slam_filter_launch(slam_ctx* ctx, const int32_t* d_idx, const int32_t* d_dist, int64_t N, int mode, double param,
                        uint8_t* d_keep);

@@ -11,7 +11,9 @@ from .matching import (  # noqa: F401
     as_descriptors,
     cross_check_arrays,
     knn2_device,
+    knn2_device_batch,
     knn_match_arrays,
+    knn_match_arrays_batch,
     knn_match_collection,
     match_arrays,
     ratio_test_arrays,

@@ -48,6 +48,7 @@ SIGNATURES = {
     "slam_prof_enable": (c_int, [c_void_p, c_int]),
     "slam_prof_read": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_double)]),
     "slam_bf_knn2_u256": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
+    "slam_bf_knn2_batch_u256": (c_int, [c_void_p, c_int64, c_void_p]),
     "slam_bf_merge_top2": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
     "slam_bf_knn2_u256_host": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p]),
     "slam_bf_set_tuning": (c_int, [c_void_p, POINTER(c_int32), c_int]),
@@ -97,6 +98,14 @@ SIGNATURES = {
     "slam_p2p_allgather_overlapped": (c_int, [c_void_p, c_void_p, c_uint64, c_int, c_void_p, c_int, c_int]),
 }
 
+class BfSearch(ctypes.Structure):
+    """``slam_bf_search`` of include/slamhip.h: one entry of a batched search."""
+
+    _fields_ = [("d_query", c_void_p), ("N", c_int64), ("d_train", c_void_p), ("M", c_int64), ("train_base", c_int64),
+                ("d_idx", c_void_p), ("d_dist", c_void_p)]
+
+
+BF_BATCH_MAX = 32
 _lib = None
 
 

@@ -202,6 +202,43 @@ def match_arrays(source, query, dist_threshold: Optional[float] = None, ctx: Opt
     return out
 
 
+def knn2_device_batch(ctx: Context, searches) -> None:
+    """Several independent searches in ONE launch (``slam_bf_knn2_batch_u256``): ``searches`` is a sequence of
+    ``(d_query, n_query, d_train, n_train, d_idx, d_dist[, train_base])`` with device buffers, at most 32 entries.
+    Each table comes out bit-identical to ``knn2_device`` on the same arguments."""
+    from ._lib import BF_BATCH_MAX, BfSearch
+
+    searches = list(searches)
+    if len(searches) > BF_BATCH_MAX:
+        raise ValueError(f"at most {BF_BATCH_MAX} searches per launch")
+    arr = (BfSearch * max(len(searches), 1))()
+    for i, sr in enumerate(searches):
+        dq, n, dt, m, di, dd = sr[:6]
+        arr[i] = BfSearch(dq.ptr if n else None, n, dt.ptr if m else None, m, sr[6] if len(sr) > 6 else 0, di.ptr, dd.ptr)
+    check(ctx.lib.slam_bf_knn2_batch_u256(ctx.handle, len(searches), arr))
+
+
+def knn_match_arrays_batch(pairs, ctx: Optional[Context] = None):
+    """``knn_match_arrays(query, train, 2)`` for several independent (query, train) pairs with ONE kernel launch:
+    candidate verifications, or the two directions of a cross check.  Returns a list of (idx [N,2], dist [N,2])."""
+    ctx = ctx or default_context()
+    prepared = [(as_descriptors(q), as_descriptors(t)) for q, t in pairs]
+    bufs, searches = [], []
+    try:
+        for q, t in prepared:
+            dq, dt = DeviceDescriptors(ctx, q), DeviceDescriptors(ctx, t)
+            tab = Top2Table(ctx, q.shape[0])
+            bufs.append((dq, dt, tab))
+            searches.append((dq.buf, q.shape[0], dt.buf, t.shape[0], tab.idx, tab.dist))
+        knn2_device_batch(ctx, searches)
+        return [tab.download() if q.shape[0] else (np.zeros((0, 2), np.int32), np.zeros((0, 2), np.int32))
+                for (q, _), (_, _, tab) in zip(prepared, bufs)]
+    finally:
+        for dq, dt, tab in bufs:
+            for o in (tab, dq, dt):
+                o.free()
+
+
 def ratio_test_arrays(query, train, ratio: float = 0.75, ctx: Optional[Context] = None):
     """knn=2 + Lowe ratio test: (queryIdx, trainIdx, distance) of queries with d0 < ratio * d1."""
     q, t = as_descriptors(query), as_descriptors(train)

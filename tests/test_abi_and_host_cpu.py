@@ -285,3 +285,38 @@ def test_peer_map_failure_reaches_every_rank():
         assert good.closed == 4
     finally:
         L._lib = old
+
+
+def test_map_discovery_skips_decoys_and_names_what_it_found(tmp_path):
+    """backend.Map comes from the REFERENCE's backend.py only: a file of that name that does not define Map together
+    with NUM_ACTIVE_KEYFRAMES and MIN_DIST_THRESHOLD (backend.py:10-12) is not even executed, the error names every
+    candidate that was turned away, and a file that does carry the marks is taken from behind the decoys."""
+    import importlib
+    import sys
+
+    import backend
+
+    decoy = tmp_path / "decoy"
+    decoy.mkdir()
+    (decoy / "backend.py").write_text("raise SystemExit('the decoy was executed')\nclass Map: pass\n")
+    half = tmp_path / "half"
+    half.mkdir()
+    (half / "backend.py").write_text("NUM_ACTIVE_KEYFRAMES = 7\nclass Map:\n    pass\n")           # no MIN_DIST_THRESHOLD
+    standin = tmp_path / "ref"
+    standin.mkdir()
+    (standin / "backend.py").write_text("NUM_ACTIVE_KEYFRAMES = 7\nMIN_DIST_THRESHOLD = 0.2\n\nclass Map:\n    marker = 'stand-in'\n")
+    saved = list(sys.path)
+    try:
+        backend.__dict__.pop("Map", None)
+        sys.path[:0] = [str(decoy), str(half)]
+        with pytest.raises(ImportError) as err:
+            backend.Map
+        msg = str(err.value)
+        assert str(decoy) in msg and str(half) in msg and "MIN_DIST_THRESHOLD" in msg
+        sys.path.append(str(standin))
+        backend.__dict__.pop("Map", None)
+        assert backend.Map.marker == "stand-in"
+    finally:
+        sys.path[:] = saved
+        backend.__dict__.pop("Map", None)
+        importlib.invalidate_caches()

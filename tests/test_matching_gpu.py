@@ -404,3 +404,71 @@ def test_keyframe_database_matches_collection_semantics(gpu_ctx):
     e = db.query(np.zeros((0, 32), np.uint8), 2)
     assert all(a.shape == (0, 2) for a in e)
     db.free()
+
+
+def test_batched_searches_equal_single_launches_and_the_oracle(gpu_ctx):
+    """slam_bf_knn2_batch_u256: B independent (query, train) searches in ONE launch - ragged sizes from one row to
+    several tiles, an empty query side, an empty train side, ties across chunk boundaries, a train_base - each table
+    bit-identical to its own slam_bf_knn2_u256 launch and to the oracle."""
+    import slamhip
+    from oracle import oracle
+
+    ctx = gpu_ctx
+    rng = np.random.default_rng(31)
+    shapes = [(200, 200), (1, 1), (4096, 4096), (777, 3), (5, 9000), (0, 50), (60, 0), (300, 1500), (2500, 2500), (64, 16500)]
+    pairs = []
+    for n, m in shapes:
+        q = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+        t = rng.integers(0, 256, (m, 32), dtype=np.uint8)
+        if n > 4 and m > 600:
+            t[m - 1] = t[3]
+            t[m // 2] = t[3]
+            q[2] = t[3]                       # a three-way tie at distance 0 spread over the chunks
+        pairs.append((q, t))
+    got = slamhip.knn_match_arrays_batch(pairs, ctx=ctx)
+    assert len(got) == len(shapes)
+    for (q, t), (idx, dist), (n, m) in zip(pairs, got, shapes):
+        assert idx.shape == (n, 2) and dist.shape == (n, 2)
+        if n == 0:
+            continue
+        sidx, sdist = slamhip.knn_match_arrays(q, t, 2, ctx=ctx)
+        assert np.array_equal(idx, sidx) and np.array_equal(dist, sdist), (n, m)
+        ridx, rdist = oracle.bf_knn_c(q, t, 2, threads=8)
+        assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist), (n, m)
+    # device-pointer form with a train_base, twice in a row (the merge state must come back clean), next to single launches
+    q, t = pairs[2]
+    dq, dt = slamhip.DeviceDescriptors(ctx, q), slamhip.DeviceDescriptors(ctx, t)
+    tabs = [slamhip.Top2Table(ctx, 4096) for _ in range(3)]
+    for _ in range(2):
+        slamhip.knn2_device_batch(ctx, [(dq.buf, 4096, dt.buf, 4096, tabs[0].idx, tabs[0].dist, 1000),
+                                        (dt.buf, 4096, dq.buf, 4096, tabs[1].idx, tabs[1].dist)])
+        slamhip.knn2_device(ctx, dq.buf, 4096, dt.buf, 4096, tabs[2].idx, tabs[2].dist, 1000)
+        a, b = tabs[0].download(), tabs[2].download()
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[0].min() >= 1000
+        ridx, rdist = oracle.bf_knn_c(t, q, 2, threads=8)
+        r = tabs[1].download()
+        assert np.array_equal(r[0], ridx) and np.array_equal(r[1], rdist)
+    for o in (*tabs, dq, dt):
+        o.free()
+    # limits and misuse are reported, not launched
+    import ctypes
+    from slamhip._lib import BfSearch
+    lib = ctx.lib
+    assert lib.slam_bf_knn2_batch_u256(ctx.handle, 0, None) == 0
+    assert lib.slam_bf_knn2_batch_u256(ctx.handle, 33, (BfSearch * 33)()) == -1
+    assert lib.slam_bf_knn2_batch_u256(ctx.handle, 1, None) == -1
+    bad = (BfSearch * 1)(BfSearch(None, 5, None, 5, 0, None, None))
+    assert lib.slam_bf_knn2_batch_u256(ctx.handle, 1, bad) == -1
+    try:
+        ctx.set_tuning(R=2)
+        with pytest.raises(slamhip.SlamHipError):
+            slamhip.knn_match_arrays_batch(pairs[:1], ctx=ctx)
+    finally:
+        ctx.set_tuning()
+    # sixteen 4096 x 4096 searches (BASELINE configs[1]) in one launch, all against the oracle on sampled rows
+    many = [(rng.integers(0, 256, (4096, 32), dtype=np.uint8), rng.integers(0, 256, (4096, 32), dtype=np.uint8)) for _ in range(16)]
+    out = slamhip.knn_match_arrays_batch(many, ctx=ctx)
+    for (q, t), (idx, dist) in zip(many, out):
+        sel = rng.choice(4096, 64, replace=False)
+        ridx, rdist = oracle.bf_knn_c(q[sel], t, 2, threads=8)
+        assert np.array_equal(idx[sel], ridx) and np.array_equal(dist[sel], rdist)

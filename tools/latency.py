@@ -111,3 +111,24 @@ for O in (50, 200, 256, 257, 1000):
           f"{cpu_ms * 1e3:7.1f} us ({acc_c} steps) | max pose difference {np.abs(got - Tc).max():.1e}, same inlier set: {same}")
     for b in d:
         b.free()
+
+# several frame-sized searches in ONE launch (slam_bf_knn2_batch_u256) against the same searches one launch at a time
+for n, B in ((200, 2), (4096, 16), (1000, 8)):
+    qs = [slamhip.DeviceDescriptors(ctx, rng.integers(0, 256, (n, 32), dtype=np.uint8)) for _ in range(B)]
+    ts = [slamhip.DeviceDescriptors(ctx, rng.integers(0, 256, (n, 32), dtype=np.uint8)) for _ in range(B)]
+    tabs = [slamhip.Top2Table(ctx, n) for _ in range(B)]
+    one = lambda: [slamhip.knn2_device(ctx, qs[i].buf, n, ts[i].buf, n, tabs[i].idx, tabs[i].dist) for i in range(B)]
+    bat = lambda: slamhip.knn2_device_batch(ctx, [(qs[i].buf, n, ts[i].buf, n, tabs[i].idx, tabs[i].dist) for i in range(B)])
+    res = {}
+    for name, f in (("one launch each", one), ("ONE launch", bat)):
+        for _ in range(20):
+            f()
+        ctx.sync()
+        ctx.timer_start()
+        for _ in range(100):
+            f()
+        res[name] = ctx.timer_stop() / 100 * 1e3
+    print(f"{B:2d} searches of {n} x {n}: {res['one launch each']:8.1f} us one launch each ({B * n * n / res['one launch each'] * 1e6:.2e} pairs/s), "
+          f"{res['ONE launch']:8.1f} us in one launch ({B * n * n / res['ONE launch'] * 1e6:.2e} pairs/s)")
+    for o in (*qs, *ts, *tabs):
+        o.free()
