@@ -300,6 +300,35 @@ SLAM_API int slam_ba_backsub_f64(slam_ctx* ctx, int64_t L, const int32_t* d_pt_p
                                  const int32_t* d_obs_pose, const double* d_rec, const double* d_E,
                                  const double* d_bl, const double* d_dp, double* d_dl);
 
+/* A whole window bundle adjustment in ONE launch: Levenberg-Marquardt with Schur complement as a persistent kernel of a
+ * few dozen workgroups - the phases of slam_ba_reduce_f64 separated by grid barriers, the dense L D L^T solve of the
+ * reduced camera system in LDS, the exp() update, the candidate's cost and the accept / reject decisions all on the
+ * device; nothing crosses PCIe between trials (extension: backend.py:101-103 is an empty class over a Map of
+ * NUM_ACTIVE_KEYFRAMES = 7 keyframes, backend.py:11).  For windows of at most SLAM_BA_LM_MAX_FREE moving poses (a 96 x 96
+ * system), 64 poses and SLAM_BA_LM_MAX_OBS observations; larger ones use slam_ba_reduce_f64 / slam_ba_backsub_f64 with
+ * a host solve.
+ *   d_poses2  [2][K,12]  in: the state in the first half;  d_points2 [2][L,3] likewise.  out: the optimised state is in
+ *             half `d_stats[6]` of both (the halves swap roles on every accepted step).
+ *   index tables as slam_ba_reduce_f64 (obs_pose / obs_point [O], pt_ptr [L+1] / pt_obs [O], ps_ptr [K+1] / ps_obs [O]);
+ *             a (pose, point) pair may be observed once; the (pose, point) -> observation table is built on the device.
+ *   d_free_poses int32 [n_free], ascending: the poses that move (the others hold the gauge).
+ *   d_work    scratch of slam_ba_optimize_workspace(K, L, O) bytes, 16-byte aligned.
+ *   d_stats   double [8]: initial cost, final cost, accepted steps, trials, final lambda, status (0 = ok; all NaN until the
+ *             launch has completed, 1 if the launch was abandoned), result half, workgroups used.
+ * Schedule: lambda0 = 1e-5 max diag(H of the free poses and of the points); `iterations` iterations of up to 10 trials;
+ * rho = (cost - cost_new) / (dx.(lambda dx - b) + 1e-3); accepted: lambda *= max(1/3, min(1 - (2 rho - 1)^3, 2/3));
+ * rejected (or a factorisation that fails): lambda *= ni, ni *= 2.  Every sum is formed in a fixed order: two runs
+ * give identical bits.  Asynchronous on the ctx stream. */
+#define SLAM_BA_LM_MAX_FREE 16
+#define SLAM_BA_LM_MAX_OBS (1 << 17)
+SLAM_API int slam_ba_optimize_workspace(int64_t K, int64_t L, int64_t O, uint64_t* bytes);
+SLAM_API int slam_ba_optimize_f64(slam_ctx* ctx, int64_t K, int64_t L, int64_t O, const int32_t* d_obs_pose,
+                                  const int32_t* d_obs_point, const double* d_meas, const int32_t* d_pt_ptr,
+                                  const int32_t* d_pt_obs, const int32_t* d_ps_ptr, const int32_t* d_ps_obs,
+                                  const int32_t* d_free_poses, int64_t n_free, double fx, double fy, double cx, double cy,
+                                  double huber_delta, int iterations, double* d_poses2, double* d_points2, void* d_work,
+                                  uint64_t work_bytes, double* d_stats);
+
 /* ---- multi-GPU: RCCL all-gather of per-shard result rows ---------------- */
 #define SLAM_COMM_ID_BYTES 128
 SLAM_API int slam_comm_version(int* version); /* ncclGetVersion of the librccl that was loaded (e.g. 22703); needs no GPU */

@@ -457,3 +457,77 @@ def ba_backsub_np(red: dict, obs_pose, obs_point, dp) -> np.ndarray:
     dl = np.einsum("lab,lb->la", red["E"], tmp)
     dl[~red["seen"]] = 0.0
     return dl
+
+
+def ba_lm_np(poses12, points, obs_pose, obs_point, meas, fx, fy, cx, cy, iterations: int = 10, fixed_poses=(0,),
+             huber_delta: float = 0.0):
+    """The window bundle adjustment the product runs on the device, as a CPU loop around ``ba_schur_np`` /
+    ``ba_backsub_np`` (C-oracle residuals and Jacobians, numpy everything else): the TRAJECTORY oracle of
+    ``slam_ba_optimize_f64`` and of the host-driven device form.
+
+    Schedule (the one the pose-only refinement takes from g2o's OptimizationAlgorithmLevenberg, applied to the joint
+    problem): lambda0 = 1e-5 max(diag Hpp of the free poses, diag Hll); per iteration up to 10 trials of the damped,
+    Schur-reduced system over the free poses; dl by back-substitution; T <- exp([w, v]) T, X <- X + dl;
+    rho = (cost - cost_new) / (dp.(lambda dp - bp) + dl.(lambda dl - bl) + 1e-3); accepted iff rho > 0 and finite:
+    lambda *= max(1/3, min(1 - (2 rho - 1)^3, 2/3)), ni = 2; rejected: lambda *= ni, ni *= 2; an iteration without an
+    accepted step ends the run.  Returns (T [K,4,4], X [L,3], cost0, cost, accepted, lambdas of the accepted steps)."""
+    P = np.ascontiguousarray(poses12, np.float64).reshape(-1, 12)
+    K = P.shape[0]
+    T = np.tile(np.eye(4), (K, 1, 1))
+    T[:, :3, :4] = P.reshape(K, 3, 4)
+    X = np.array(points, np.float64).reshape(-1, 3)
+    op, ol = np.asarray(obs_pose, np.int32), np.asarray(obs_point, np.int32)
+    free = np.ones(K, bool)
+    free[list(fixed_poses)] = False
+    fidx = np.flatnonzero(free)
+    rt = lambda Tm: Tm[:, :3, :4].reshape(K, 12)
+
+    def cost_at(Tm, Xm):
+        e, _, _ = reproj_rj_c(rt(Tm), Xm, op, ol, meas, fx, fy, cx, cy, with_point=False)
+        return _huber_rho((e * e).sum(1), huber_delta)
+
+    red = ba_schur_np(rt(T), X, op, ol, meas, fx, fy, cx, cy, huber_delta, 1.0)
+    cost0 = cost = red["cost"]
+    # diag of the undamped blocks: S[k,k] + W[k,k] - lam I = Hpp[k]; rebuild Hpp / Hll diagonals from the linearisation
+    e, Jp, Jq = reproj_rj_c(rt(T), X, op, ol, meas, fx, fy, cx, cy, with_point=True)
+    s = np.sqrt((e * e).sum(1))
+    w = np.where((huber_delta > 0) & (s > huber_delta), huber_delta / np.maximum(s, 1e-300), 1.0)
+    dpp = np.zeros((K, 6)); np.add.at(dpp, op, w[:, None] * (Jp * Jp).sum(1))
+    dll = np.zeros((X.shape[0], 3)); np.add.at(dll, ol, w[:, None] * (Jq * Jq).sum(1))
+    lam = 1e-5 * max(float(dpp[fidx].max(initial=0.0)), float(dll.max(initial=0.0)), 1e-12)
+    ni, accepted, lams = 2.0, 0, []
+    if len(fidx) == 0:
+        return T, X, cost0, cost, 0, lams
+    for _ in range(iterations):
+        ok = False
+        for _trial in range(10):
+            red = ba_schur_np(rt(T), X, op, ol, meas, fx, fy, cx, cy, huber_delta, lam)
+            Sf = red["S"][np.ix_(fidx, fidx)].transpose(0, 2, 1, 3).reshape(6 * len(fidx), 6 * len(fidx))
+            try:
+                dpf = np.linalg.solve(Sf, red["rhs"][fidx].reshape(-1)).reshape(-1, 6)
+                if not np.isfinite(dpf).all():
+                    raise np.linalg.LinAlgError
+            except np.linalg.LinAlgError:
+                lam, ni = lam * ni, ni * 2
+                continue
+            dp = np.zeros((K, 6)); dp[fidx] = dpf
+            dl = ba_backsub_np(red, op, ol, dp)
+            Tn = np.stack([se3_exp_np(dp[k]) @ T[k] for k in range(K)])
+            Xn = X + dl
+            new = cost_at(Tn, Xn)
+            scale = float((dp * (lam * dp - red["bp"])).sum() + (dl * (lam * dl - red["bl"])).sum()) + 1e-3
+            rho = (red["cost"] - new) / scale
+            if rho > 0 and np.isfinite(new):
+                T, X, cost = Tn, Xn, new
+                lams.append(lam)
+                lam *= max(1.0 / 3.0, min(1.0 - (2.0 * rho - 1.0) ** 3, 2.0 / 3.0))
+                ni = 2.0
+                accepted += 1
+                ok = True
+                break
+            lam, ni = lam * ni, ni * 2
+            if not np.isfinite(lam):
+                break
+        if not ok:
+            break
+    return T, X, cost0, cost, accepted, lams

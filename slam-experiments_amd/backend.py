@@ -118,11 +118,17 @@ class Backend:
         """Bundle adjustment over a window of keyframes and their landmarks (``optimizer.optimize(10)`` in
         spirit, ``frontend.py:362``; the reference's ``Backend`` has no body, ``backend.py:101-103``).
 
-        With ``on_device`` (default) the linearisation, the elimination of the landmarks, the blocks of the
-        reduced camera system and the back-substitution run on the GPU (``slam_ba_reduce_f64`` /
-        ``slam_ba_backsub_f64``) and the host solves the 6K x 6K system; otherwise only residuals and
-        Jacobians come from the GPU and numpy does the rest.  Returns ``slamhip.ba.BAResult``."""
-        fn = _ba.bundle_adjust_device if on_device else _ba.bundle_adjust
+        With ``on_device`` (default) a window of at most 16 moving poses and 20 000 observations (the reference keeps
+        7 keyframes, ``backend.py:11``) is optimised in ONE kernel launch (``slam_ba_optimize_f64``: the whole LM loop,
+        dense solve included, on the device); larger windows run the linearisation, the elimination of the landmarks,
+        the blocks of the reduced camera system and the back-substitution on the GPU (``slam_ba_reduce_f64`` /
+        ``slam_ba_backsub_f64``) and solve the 6K x 6K system on the host.  With ``on_device=False`` only residuals
+        and Jacobians come from the GPU and numpy does the rest.  Returns ``slamhip.ba.BAResult``."""
+        fn = _ba.bundle_adjust
+        if on_device:
+            n_free = len(poses) - len(set(fixed_poses))
+            one_launch = n_free <= _ba.ONE_LAUNCH_MAX_FREE and len(obs_pose_idx) <= _ba.ONE_LAUNCH_MAX_OBS and len(poses) <= 64
+            fn = _ba.bundle_adjust_one_launch if one_launch else _ba.bundle_adjust_device
         return fn(poses, points, obs_pose_idx, obs_point_idx, meas, (fx, fy, cx, cy), iterations, fixed_poses,
                   huber_delta, ctx=self.ctx)
 

@@ -40,15 +40,13 @@ __device__ __forceinline__ double ba_wave_sum(double v) {
     return v;
 }
 
-__global__ __launch_bounds__(BA_THREADS) void ba_obs_kernel(const double* __restrict__ poses,
-                                                            const double* __restrict__ points,
-                                                            const int* __restrict__ obs_pose,
-                                                            const int* __restrict__ obs_point,
-                                                            const double2* __restrict__ meas, int O, ba_cam cam,
-                                                            double delta, int K, int L,
-                                                            unsigned int* __restrict__ index_errors,
-                                                            double* __restrict__ rec) {
-    const int o = blockIdx.x * BA_THREADS + threadIdx.x;
+// (the *_body functions take the block index as an argument: blockIdx.x of the per-phase kernels below, a loop variable
+// of the persistent kernel in ba_lm.hip's grid form at the end of this file)
+__device__ __forceinline__ void ba_obs_body(const double* __restrict__ poses, const double* __restrict__ points,
+                                            const int* __restrict__ obs_pose, const int* __restrict__ obs_point,
+                                            const double2* __restrict__ meas, int O, ba_cam cam, double delta, int K, int L,
+                                            unsigned int* __restrict__ index_errors, double* __restrict__ rec, int block) {
+    const int o = block * BA_THREADS + threadIdx.x;
     if (o >= O) return;
     int k = obs_pose[o], l = obs_point[o];
     bool bad = false;
@@ -105,13 +103,22 @@ __global__ __launch_bounds__(BA_THREADS) void ba_obs_kernel(const double* __rest
     r[72] = rho;
 }
 
+__global__ __launch_bounds__(BA_THREADS) void ba_obs_kernel(const double* __restrict__ poses,
+                                                            const double* __restrict__ points,
+                                                            const int* __restrict__ obs_pose,
+                                                            const int* __restrict__ obs_point,
+                                                            const double2* __restrict__ meas, int O, ba_cam cam,
+                                                            double delta, int K, int L,
+                                                            unsigned int* __restrict__ index_errors,
+                                                            double* __restrict__ rec) {
+    ba_obs_body(poses, points, obs_pose, obs_point, meas, O, cam, delta, K, L, index_errors, rec, (int)blockIdx.x);
+}
+
 // per point: Hll, bl over its observations (CSR row, ascending), E = (Hll + lam I)^-1, Y_o = Hpl_o E
-__global__ __launch_bounds__(BA_THREADS) void ba_point_kernel(const int* __restrict__ pt_ptr,
-                                                              const int* __restrict__ pt_obs, int L, double lam,
-                                                              double* __restrict__ rec, double* __restrict__ E,
-                                                              double* __restrict__ bl,
-                                                              double* __restrict__ hll_diag /*[L,3] or null*/) {
-    const int l = blockIdx.x * BA_THREADS + threadIdx.x;
+__device__ __forceinline__ void ba_point_body(const int* __restrict__ pt_ptr, const int* __restrict__ pt_obs, int L, double lam,
+                                              double* __restrict__ rec, double* __restrict__ E, double* __restrict__ bl,
+                                              double* __restrict__ hll_diag /*[L,3] or null*/, int block) {
+    const int l = block * BA_THREADS + threadIdx.x;
     if (l >= L) return;
     double h[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
     const int a0 = pt_ptr[l], a1 = pt_ptr[l + 1];
@@ -151,6 +158,14 @@ __global__ __launch_bounds__(BA_THREADS) void ba_point_kernel(const int* __restr
     }
 }
 
+__global__ __launch_bounds__(BA_THREADS) void ba_point_kernel(const int* __restrict__ pt_ptr,
+                                                              const int* __restrict__ pt_obs, int L, double lam,
+                                                              double* __restrict__ rec, double* __restrict__ E,
+                                                              double* __restrict__ bl,
+                                                              double* __restrict__ hll_diag /*[L,3] or null*/) {
+    ba_point_body(pt_ptr, pt_obs, L, lam, rec, E, bl, hll_diag, (int)blockIdx.x);
+}
+
 // block-wide fixed-order sum of NT per-thread accumulators into out[NT] (shared), all threads return after it
 template <int NT>
 __device__ __forceinline__ void ba_block_sum(const double (&acc)[NT], double (*sw)[NT], double* out) {
@@ -167,18 +182,11 @@ __device__ __forceinline__ void ba_block_sum(const double (&acc)[NT], double (*s
 }
 
 // one block per pose k: Hpp (21), bp (6), y = sum Y_o bl (6), cost (1) over the pose's observation list
-__global__ __launch_bounds__(BA_THREADS) void ba_pose_kernel(const int* __restrict__ ps_ptr,
-                                                             const int* __restrict__ ps_obs,
-                                                             const int* __restrict__ obs_point,
-                                                             const double* __restrict__ rec,
-                                                             const double* __restrict__ bl,
-                                                             double* __restrict__ Hpp /*[K,21]*/,
-                                                             double* __restrict__ bp /*[K,6]*/,
-                                                             double* __restrict__ ybl /*[K,6]*/,
-                                                             double* __restrict__ cost /*[K]*/) {
-    __shared__ double sw[4][34];
-    __shared__ double out[34];
-    const int k = blockIdx.x;
+__device__ __forceinline__ void ba_pose_body(const int* __restrict__ ps_ptr, const int* __restrict__ ps_obs,
+                                             const int* __restrict__ obs_point, const double* __restrict__ rec,
+                                             const double* __restrict__ bl, double* __restrict__ Hpp /*[K,21]*/,
+                                             double* __restrict__ bp /*[K,6]*/, double* __restrict__ ybl /*[K,6]*/,
+                                             double* __restrict__ cost /*[K]*/, double (*sw)[34], double* out, const int k) {
     double acc[34];
 #pragma unroll
     for (int i = 0; i < 34; i++) acc[i] = 0.0;
@@ -201,17 +209,30 @@ __global__ __launch_bounds__(BA_THREADS) void ba_pose_kernel(const int* __restri
     if (threadIdx.x == 0) cost[k] = out[33];
 }
 
-// one block per pose pair (k1 <= k2): W[k1,k2] = sum over points seen by both of Y_(k1,l) Hpl_(k2,l)^T (6x6)
-__global__ __launch_bounds__(BA_THREADS) void ba_pair_kernel(const int* __restrict__ ps_ptr,
+__global__ __launch_bounds__(BA_THREADS) void ba_pose_kernel(const int* __restrict__ ps_ptr,
                                                              const int* __restrict__ ps_obs,
                                                              const int* __restrict__ obs_point,
-                                                             const int* __restrict__ lookup /*[K,L] obs of (pose, point) or -1*/,
-                                                             int K, int L, const double* __restrict__ rec,
-                                                             double* __restrict__ W /*[K,K,36]*/) {
-    __shared__ double sw[4][36];
-    __shared__ double out[36];
-    const int k1 = blockIdx.x, k2 = blockIdx.y;
-    if (k2 < k1) return;
+                                                             const double* __restrict__ rec,
+                                                             const double* __restrict__ bl,
+                                                             double* __restrict__ Hpp /*[K,21]*/,
+                                                             double* __restrict__ bp /*[K,6]*/,
+                                                             double* __restrict__ ybl /*[K,6]*/,
+                                                             double* __restrict__ cost /*[K]*/) {
+    __shared__ double sw[4][34];
+    __shared__ double out[34];
+    ba_pose_body(ps_ptr, ps_obs, obs_point, rec, bl, Hpp, bp, ybl, cost, sw, out, (int)blockIdx.x);
+}
+
+// one block per pose pair (k1 <= k2): W[k1,k2] = sum over points seen by both of Y_(k1,l) Hpl_(k2,l)^T (6x6).
+// `pair` runs over the K (K + 1) / 2 upper blocks in row-major order (round 2 launched K x K blocks and half returned).
+__device__ __forceinline__ void ba_pair_body(const int* __restrict__ ps_ptr, const int* __restrict__ ps_obs,
+                                             const int* __restrict__ obs_point,
+                                             const int* __restrict__ lookup /*[K,L] obs of (pose, point) or -1*/, int K, int L,
+                                             const double* __restrict__ rec, double* __restrict__ W /*[K,K,36]*/,
+                                             double (*sw)[36], double* out, int pair) {
+    int k1 = 0;
+    while (pair >= K - k1) { pair -= K - k1; k1++; }
+    const int k2 = k1 + pair;
     double acc[36];
 #pragma unroll
     for (int i = 0; i < 36; i++) acc[i] = 0.0;
@@ -231,16 +252,23 @@ __global__ __launch_bounds__(BA_THREADS) void ba_pair_kernel(const int* __restri
     if (threadIdx.x < 36) W[((size_t)k1 * K + k2) * 36 + threadIdx.x] = out[threadIdx.x];
 }
 
+__global__ __launch_bounds__(BA_THREADS) void ba_pair_kernel(const int* __restrict__ ps_ptr,
+                                                             const int* __restrict__ ps_obs,
+                                                             const int* __restrict__ obs_point,
+                                                             const int* __restrict__ lookup, int K, int L,
+                                                             const double* __restrict__ rec, double* __restrict__ W) {
+    __shared__ double sw[4][36];
+    __shared__ double out[36];
+    ba_pair_body(ps_ptr, ps_obs, obs_point, lookup, K, L, rec, W, sw, out, (int)blockIdx.x);
+}
+
 // per point: dl = E (-bl - sum_{o of l} Hpl_o^T dp_pose(o))
-__global__ __launch_bounds__(BA_THREADS) void ba_backsub_kernel(const int* __restrict__ pt_ptr,
-                                                                const int* __restrict__ pt_obs,
-                                                                const int* __restrict__ obs_pose, int L,
-                                                                const double* __restrict__ rec,
-                                                                const double* __restrict__ E,
-                                                                const double* __restrict__ bl,
-                                                                const double* __restrict__ dp /*[K,6]*/,
-                                                                double* __restrict__ dl /*[L,3]*/) {
-    const int l = blockIdx.x * BA_THREADS + threadIdx.x;
+__device__ __forceinline__ void ba_backsub_body(const int* __restrict__ pt_ptr, const int* __restrict__ pt_obs,
+                                                const int* __restrict__ obs_pose, int L, const double* __restrict__ rec,
+                                                const double* __restrict__ E, const double* __restrict__ bl,
+                                                const double* __restrict__ dp /*[K,6]*/, double* __restrict__ dl /*[L,3]*/,
+                                                int block) {
+    const int l = block * BA_THREADS + threadIdx.x;
     if (l >= L) return;
     double t[3] = {-bl[(size_t)l * 3], -bl[(size_t)l * 3 + 1], -bl[(size_t)l * 3 + 2]};
     const int a0 = pt_ptr[l], a1 = pt_ptr[l + 1];
@@ -259,17 +287,23 @@ __global__ __launch_bounds__(BA_THREADS) void ba_backsub_kernel(const int* __res
     for (int c = 0; c < 3; c++) dl[(size_t)l * 3 + c] = seen ? e[c * 3] * t[0] + e[c * 3 + 1] * t[1] + e[c * 3 + 2] * t[2] : 0.0;
 }
 
+__global__ __launch_bounds__(BA_THREADS) void ba_backsub_kernel(const int* __restrict__ pt_ptr,
+                                                                const int* __restrict__ pt_obs,
+                                                                const int* __restrict__ obs_pose, int L,
+                                                                const double* __restrict__ rec,
+                                                                const double* __restrict__ E,
+                                                                const double* __restrict__ bl,
+                                                                const double* __restrict__ dp /*[K,6]*/,
+                                                                double* __restrict__ dl /*[L,3]*/) {
+    ba_backsub_body(pt_ptr, pt_obs, obs_pose, L, rec, E, bl, dp, dl, (int)blockIdx.x);
+}
+
 // robust cost only (an LM trial needs nothing else from the candidate state): one block per pose
-__global__ __launch_bounds__(BA_THREADS) void ba_cost_kernel(const double* __restrict__ poses,
-                                                             const double* __restrict__ points,
-                                                             const int* __restrict__ obs_point,
-                                                             const double2* __restrict__ meas,
-                                                             const int* __restrict__ ps_ptr,
-                                                             const int* __restrict__ ps_obs, ba_cam cam, double delta,
-                                                             double* __restrict__ cost /*[K]*/) {
-    __shared__ double sw[4][1];
-    __shared__ double out[1];
-    const int k = blockIdx.x;
+__device__ __forceinline__ void ba_cost_body(const double* __restrict__ poses, const double* __restrict__ points,
+                                             const int* __restrict__ obs_point, const double2* __restrict__ meas,
+                                             const int* __restrict__ ps_ptr, const int* __restrict__ ps_obs, ba_cam cam,
+                                             double delta, double* __restrict__ cost /*[K]*/, double (*sw)[1], double* out,
+                                             const int k) {
     const double* P = poses + (size_t)k * 12;
     double acc[1] = {0.0};
     for (int i = ps_ptr[k] + threadIdx.x; i < ps_ptr[k + 1]; i += BA_THREADS) {
@@ -291,6 +325,18 @@ __global__ __launch_bounds__(BA_THREADS) void ba_cost_kernel(const double* __res
     }
     ba_block_sum<1>(acc, sw, out);
     if (threadIdx.x == 0) cost[k] = out[0];
+}
+
+__global__ __launch_bounds__(BA_THREADS) void ba_cost_kernel(const double* __restrict__ poses,
+                                                             const double* __restrict__ points,
+                                                             const int* __restrict__ obs_point,
+                                                             const double2* __restrict__ meas,
+                                                             const int* __restrict__ ps_ptr,
+                                                             const int* __restrict__ ps_obs, ba_cam cam, double delta,
+                                                             double* __restrict__ cost /*[K]*/) {
+    __shared__ double sw[4][1];
+    __shared__ double out[1];
+    ba_cost_body(poses, points, obs_point, meas, ps_ptr, ps_obs, cam, delta, cost, sw, out, (int)blockIdx.x);
 }
 
 extern "C" int slam_ba_cost_f64(slam_ctx* ctx, const double* d_poses, int64_t K, const double* d_points,
@@ -333,8 +379,8 @@ extern "C" int slam_ba_reduce_f64(slam_ctx* ctx, const double* d_poses, int64_t 
         d_pt_ptr, d_pt_obs, (int)L, lambda, d_rec, d_E, d_bl, d_hll_diag);
     ba_pose_kernel<<<(unsigned)K, BA_THREADS, 0, ctx->stream>>>(d_ps_ptr, d_ps_obs, d_obs_point, d_rec, d_bl, d_Hpp,
                                                                  d_bp, d_ybl, d_cost);
-    ba_pair_kernel<<<dim3((unsigned)K, (unsigned)K), BA_THREADS, 0, ctx->stream>>>(d_ps_ptr, d_ps_obs, d_obs_point,
-                                                                                    d_lookup, (int)K, (int)L, d_rec, d_W);
+    ba_pair_kernel<<<(unsigned)(K * (K + 1) / 2), BA_THREADS, 0, ctx->stream>>>(d_ps_ptr, d_ps_obs, d_obs_point, d_lookup, (int)K,
+                                                                                 (int)L, d_rec, d_W);
     SLAM_HIP(hipGetLastError());
     return SLAM_OK;
 }
@@ -349,6 +395,444 @@ extern "C" int slam_ba_backsub_f64(slam_ctx* ctx, int64_t L, const int32_t* d_pt
     SLAM_HIP(hipSetDevice(ctx->device));
     ba_backsub_kernel<<<(unsigned)((L + BA_THREADS - 1) / BA_THREADS), BA_THREADS, 0, ctx->stream>>>(
         d_pt_ptr, d_pt_obs, d_obs_pose, (int)L, d_rec, d_E, d_bl, d_dp, d_dl);
+    SLAM_HIP(hipGetLastError());
+    return SLAM_OK;
+}
+
+// =====================================================================================================================
+// The whole window LM as ONE persistent launch of a few dozen workgroups (slam_ba_optimize_f64).
+//
+// Same phases as the per-phase kernels above - their bodies are called with a loop variable for the block index - but
+// nothing returns to the host between them: a grid barrier separates the phases, workgroup 0 assembles the reduced
+// system of the free poses in LDS and factors it (L D L^T, one wave), and the Levenberg-Marquardt bookkeeping is
+// replicated in every workgroup (same arithmetic on the same values), so a verdict costs no barrier of its own:
+// five barriers per accepted trial (linearise | points | camera blocks | solve | step + candidate cost), four per
+// rejected one.
+//
+// The grid barrier is the counter hand-off of cdna_hip_programming.md G16: every wave drains its stores, the
+// workgroup's barrier, then ONE lane does an agent-scope release, takes a ticket, and either opens the next generation
+// (last arriver) or polls the generation word; an agent-scope acquire and the workgroup's barrier follow.  That is what
+// makes plain loads of another workgroup's results valid afterwards (per-CU L1s and per-XCD L2s are not coherent by
+// themselves).  It needs every workgroup of the grid to be resident at once: the grid is at most 128 workgroups of 256
+// threads on a 256-CU device, far below what fits, and every poll is bounded - a workgroup that waits 2^22 polls raises
+// `abort`, which every workgroup checks behind every barrier, so a fault ends the launch instead of hanging the GPU.
+// =====================================================================================================================
+struct bg_ctl {
+    unsigned int arrive, gen;     // the grid barrier
+    int abort, solved;            // launch abandoned; did workgroup 0's factorisation succeed
+};
+
+struct bg_args {
+    int K, L, O, iterations, nfree, nblocks;
+    const int* obs_pose; const int* obs_point; const double2* meas;
+    const int* pt_ptr; const int* pt_obs; const int* ps_ptr; const int* ps_obs; const int* free_list;
+    int* lookup;
+    double* T; double* X;                                        // [2][K*12], [2][L*3]
+    double* rec; double* E; double* bl; double* hll;             // [O*BA_REC], [L*9], [L*3], [L*3]
+    double* Hpp; double* bp; double* ybl; double* costk; double* costn; double* W;   // [K*21] [K*6] [K*6] [K] [K] [K*K*36]
+    double* dp; double* dl; double* part;                        // [K*6], [L*3], [nblocks][2] (gain-ratio denominator, candidate cost)
+    bg_ctl* ctl;
+    double* stats;
+    unsigned int* index_errors;
+    ba_cam cam; double delta;
+};
+
+#define BG_TRI(i, j) ((i) * ((i) + 1) / 2 + (j))   // packed lower triangle, j <= i
+#define BG_MAXN (SLAM_BA_LM_MAX_FREE * 6)
+
+template <typename T>
+__device__ __forceinline__ T bg_load(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// returns false when the launch is being abandoned
+__device__ __forceinline__ bool bg_grid_sync(bg_ctl* c, unsigned int nblocks, unsigned int& gen) {
+    __syncthreads();                                         // every wave's stores are issued and drained
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        const unsigned int ticket = __hip_atomic_fetch_add(&c->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ticket == nblocks - 1) {
+            __hip_atomic_store(&c->arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(&c->gen, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            unsigned int polls = 0;
+            while (__hip_atomic_load(&c->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
+                if (++polls > (1u << 22) || __hip_atomic_load(&c->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    __hip_atomic_store(&c->abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    gen++;
+    __syncthreads();
+    return bg_load(&c->abort) == 0;
+}
+
+// W block of one pair of poses (k1 <= k2), see ba_pair_body
+__device__ __forceinline__ void bg_pair(const bg_args& a, int k1, int k2, double (*sw)[36], double* out) {
+    double acc[36];
+#pragma unroll
+    for (int i = 0; i < 36; i++) acc[i] = 0.0;
+    for (int i = a.ps_ptr[k1] + threadIdx.x; i < a.ps_ptr[k1 + 1]; i += BA_THREADS) {
+        const int o1 = a.ps_obs[i];
+        const int o2 = k1 == k2 ? o1 : a.lookup[(size_t)k2 * a.L + a.obs_point[o1]];
+        if (o2 < 0) continue;
+        const double* y = a.rec + (size_t)o1 * BA_REC + 18;
+        const double* h = a.rec + (size_t)o2 * BA_REC;
+#pragma unroll
+        for (int x = 0; x < 6; x++)
+#pragma unroll
+            for (int b = 0; b < 6; b++)
+                acc[x * 6 + b] += y[x * 3] * h[b * 3] + y[x * 3 + 1] * h[b * 3 + 1] + y[x * 3 + 2] * h[b * 3 + 2];
+    }
+    ba_block_sum<36>(acc, sw, out);
+    if (threadIdx.x < 36) a.W[((size_t)k1 * a.K + k2) * 36 + threadIdx.x] = out[threadIdx.x];
+}
+
+// exp([w, v]) * T for a 3x4 row-major pose (rotation first): the update the Jacobian of frontend.py:288-291 is the derivative for
+__device__ void bg_apply_update(const double* dx, const double* T, double* Tn) {
+    const double wx = dx[0], wy = dx[1], wz = dx[2];
+    const double th2 = wx * wx + wy * wy + wz * wz, th = sqrt(th2);
+    double sa, sb, sc;  // sin(th)/th, (1-cos)/th^2, (th-sin)/th^3
+    if (th < 1e-10) { sa = 1.0; sb = 0.5; sc = 1.0 / 6.0; }
+    else {
+        double sn, cs;
+        sincos(th, &sn, &cs);
+        sa = sn / th; sb = (1.0 - cs) / th2; sc = (th - sn) / (th2 * th);
+    }
+    const double Wm[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
+    double W2[9];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) W2[i * 3 + j] = Wm[i * 3] * Wm[j] + Wm[i * 3 + 1] * Wm[3 + j] + Wm[i * 3 + 2] * Wm[6 + j];
+    double R[9], V[9];
+    for (int i = 0; i < 9; i++) {
+        const double I = (i % 4 == 0) ? 1.0 : 0.0;
+        R[i] = I + sa * Wm[i] + sb * W2[i];
+        V[i] = I + sb * Wm[i] + sc * W2[i];
+    }
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 4; j++) Tn[i * 4 + j] = R[i * 3] * T[j] + R[i * 3 + 1] * T[4 + j] + R[i * 3 + 2] * T[8 + j];
+        Tn[i * 4 + 3] += V[i * 3] * dx[3] + V[i * 3 + 1] * dx[4] + V[i * 3 + 2] * dx[5];
+    }
+}
+
+__global__ __launch_bounds__(BA_THREADS) void ba_lm_grid_kernel(const bg_args a) {
+    __shared__ double S[BG_TRI(BG_MAXN, 0)];       // block 0: the reduced system, lower triangle packed by rows (37 KiB at 96 x 96)
+    __shared__ double rhs[BG_MAXN];
+    __shared__ double sw[4][36];
+    __shared__ double out[36];
+    __shared__ int s_solved;
+    __shared__ double sTn[64 * 12];                // the candidate poses, per workgroup (K <= 64)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, blk = (int)blockIdx.x, G = a.nblocks;
+    const int K = a.K, L = a.L, O = a.O, nf = a.nfree, n = 6 * nf;
+    bg_ctl* c = a.ctl;
+    unsigned int gen = 0;
+    // The Levenberg-Marquardt state is REPLICATED: every thread of every workgroup holds it and updates it with the same
+    // arithmetic on the same device-memory values (read behind a grid barrier), so no verdict has to be published and
+    // waited for - only the factorisation's outcome (workgroup 0's) travels through the control block.
+    int cur = 0, need_lin = 1, accepted = 0, trials = 0, iter = 0, trial = 0, done = 0;
+    double lambda = -1.0, ni = 2.0, cost = 0.0;      // lambda < 0: "not measured yet"
+
+    // ---- phase 0: the (pose, point) -> observation table, on the device ---------------------------------------------------
+    for (long long i = (long long)blk * BA_THREADS + tid; i < (long long)K * L; i += (long long)G * BA_THREADS) a.lookup[i] = -1;
+    if (!bg_grid_sync(c, G, gen)) return;
+    for (int o = blk * BA_THREADS + tid; o < O; o += G * BA_THREADS) a.lookup[(size_t)a.obs_pose[o] * L + a.obs_point[o]] = o;
+    if (!bg_grid_sync(c, G, gen)) return;
+
+    while (!done) {
+        const double lam = lambda < 0.0 ? 1.0 : lambda;             // the very first pass only measures the diagonal
+        const double* T = a.T + (size_t)cur * K * 12;
+        const double* X = a.X + (size_t)cur * L * 3;
+        double* Tn = a.T + (size_t)(1 - cur) * K * 12;
+        double* Xn = a.X + (size_t)(1 - cur) * L * 3;
+
+        // ---- linearise at the state (only when it changed: a rejected trial only changes lambda) ----------------------------
+        if (need_lin) {
+            for (int b = blk; b * BA_THREADS < O; b += G)
+                ba_obs_body(T, X, a.obs_pose, a.obs_point, a.meas, O, a.cam, a.delta, K, L, a.index_errors, a.rec, b);
+            if (!bg_grid_sync(c, G, gen)) return;
+            need_lin = 0;
+        }
+        // ---- points: Hll, bl, E = (Hll + lambda I)^-1, Y = Hpl E ---------------------------------------------------------------
+        for (int b = blk; b * BA_THREADS < L; b += G) ba_point_body(a.pt_ptr, a.pt_obs, L, lam, a.rec, a.E, a.bl, a.hll, b);
+        if (!bg_grid_sync(c, G, gen)) return;
+        // ---- per pose: Hpp, bp, y, cost; per pair of free poses: W (one workgroup per task) ---------------------------------------
+        {
+            const int npair = nf * (nf + 1) / 2;
+            for (int task = blk; task < K + npair; task += G) {
+                if (task < K) {
+                    ba_pose_body(a.ps_ptr, a.ps_obs, a.obs_point, a.rec, a.bl, a.Hpp, a.bp, a.ybl, a.costk, (double(*)[34])sw, out, task);
+                } else {
+                    int p = task - K, f1 = 0;
+                    while (p >= nf - f1) { p -= nf - f1; f1++; }
+                    bg_pair(a, a.free_list[f1], a.free_list[f1 + p], sw, out);
+                }
+                __syncthreads();
+            }
+        }
+        if (!bg_grid_sync(c, G, gen)) return;
+
+        if (lambda < 0.0) {
+            // initial damping: tau * the largest diagonal entry of the free poses' Hpp and of every Hll (every workgroup
+            // computes it for itself: a maximum does not depend on the order)
+            double v = 0.0;
+            for (int i = tid; i < L * 3; i += BA_THREADS) v = fmax(v, a.hll[i]);
+            for (int i = tid; i < nf * 6; i += BA_THREADS) {
+                const int d = i % 6;
+                v = fmax(v, a.Hpp[(size_t)a.free_list[i / 6] * 21 + d * 6 - d * (d - 1) / 2]);   // diagonal entry d of the packed upper triangle
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+            __syncthreads();
+            if (lane == 0) sw[wave][0] = v;
+            __syncthreads();
+            lambda = 1e-5 * fmax(fmax(fmax(sw[0][0], sw[1][0]), fmax(sw[2][0], sw[3][0])), 1e-12);
+            cost = 0.0;
+            for (int k = 0; k < K; k++) cost += a.costk[k];
+            if (blk == 0 && tid == 0) a.stats[0] = cost;
+            if (a.iterations <= 0 || nf == 0) done = 1;
+            __syncthreads();
+            continue;                                  // points / blocks again, now with the real lambda
+        }
+
+        // ---- workgroup 0: assemble the reduced system of the free poses in LDS and solve it -----------------------------------
+        if (blk == 0) {
+            for (int idx = tid; idx < n * n; idx += BA_THREADS) {
+                const int i = idx / n, j = idx % n, fa = i / 6, fb = j / 6, ii = i % 6, jj = j % 6;
+                if (j > i) continue;                       // S is symmetric: the lower triangle is kept
+                const int ka = a.free_list[fa], kb = a.free_list[fb];
+                double v;
+                if (fa == fb) {
+                    const int tri = jj * 6 - jj * (jj - 1) / 2 + (ii - jj);        // jj <= ii: index in the packed upper triangle of Hpp
+                    v = a.Hpp[(size_t)ka * 21 + tri] + (ii == jj ? lam : 0.0) - a.W[((size_t)ka * K + ka) * 36 + ii * 6 + jj];
+                } else {
+                    v = -a.W[((size_t)kb * K + ka) * 36 + jj * 6 + ii];            // fa > fb: the transpose of W[kb, ka]
+                }
+                S[BG_TRI(i, j)] = v;
+            }
+            for (int i = tid; i < n; i += BA_THREADS) {
+                const int k = a.free_list[i / 6];
+                rhs[i] = -a.bp[(size_t)k * 6 + i % 6] + a.ybl[(size_t)k * 6 + i % 6];
+            }
+            __syncthreads();
+            // L D L^T in place, right-looking, the whole workgroup: step j subtracts (S[i][j] / d_j) S[k][j] from every
+            // element (i, k) of the trailing triangle (a 16 x 16 thread tile walks it; column j is only read), then scales
+            // column j.  After step j column j below the diagonal holds L, the diagonal D.  (A first version gave each lane
+            // of ONE wave two rows: its inner loop is a chain of dependent LDS read-modify-writes and took ~55 us at 30 x 30.)
+            bool spd = true;
+            {
+                const int ty = tid >> 4, tx = tid & 15;
+                for (int j = 0; j < n; j++) {
+                    const double d = S[BG_TRI(j, j)];
+                    spd = spd && d > 0.0 && isfinite(d);
+                    const double inv = 1.0 / d;
+                    for (int i = j + 1 + ty; i < n; i += 16) {
+                        const double lij = S[BG_TRI(i, j)] * inv;
+                        for (int k = j + 1 + tx; k <= i; k += 16) S[BG_TRI(i, k)] -= lij * S[BG_TRI(k, j)];
+                    }
+                    __syncthreads();
+                    for (int i = j + 1 + tid; i < n; i += BA_THREADS) S[BG_TRI(i, j)] *= inv;
+                    __syncthreads();
+                }
+            }
+            if (wave == 0) {
+                for (int j = 0; j < n; j++) {            // forward: L y = rhs
+                    const double yj = rhs[j];
+#pragma unroll
+                    for (int half = 0; half < 2; half++) {
+                        const int i = lane + 64 * half;
+                        if (i > j && i < n) rhs[i] -= S[BG_TRI(i, j)] * yj;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+#pragma unroll
+                for (int half = 0; half < 2; half++) {
+                    const int i = lane + 64 * half;
+                    if (i < n) rhs[i] /= S[BG_TRI(i, i)];
+                }
+                __builtin_amdgcn_wave_barrier();
+                for (int j = n - 1; j >= 0; j--) {        // backward: L^T x = y
+                    const double xj = rhs[j];
+#pragma unroll
+                    for (int half = 0; half < 2; half++) {
+                        const int i = lane + 64 * half;
+                        if (i < j) rhs[i] -= S[BG_TRI(j, i)] * xj;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+                bool finite = true;
+#pragma unroll
+                for (int half = 0; half < 2; half++) {
+                    const int i = lane + 64 * half;
+                    if (i < n) finite = finite && isfinite(rhs[i]);
+                }
+                const bool ok = __ballot(!(spd && finite)) == 0ull;
+                if (lane == 0) s_solved = ok ? 1 : 0;
+            }
+            __syncthreads();
+            for (int i = tid; i < K * 6; i += BA_THREADS) a.dp[i] = 0.0;
+            __syncthreads();
+            if (s_solved)
+                for (int i = tid; i < n; i += BA_THREADS) a.dp[(size_t)a.free_list[i / 6] * 6 + i % 6] = rhs[i];
+            if (tid == 0) c->solved = s_solved;
+        }
+        if (!bg_grid_sync(c, G, gen)) return;
+        if (!bg_load(&c->solved)) {                    // a factorisation that fails counts as a trial
+            lambda = lam * ni; ni *= 2.0; trials++; trial++;
+            if (trial >= 10 || !isfinite(lambda)) done = 1;
+            continue;
+        }
+
+        // ---- the step and its verdict's ingredients, one thread per point: dl by back-substitution, the candidate point, its
+        //      share of the gain ratio's denominator, and the candidate's robust cost over the point's observations (every
+        //      workgroup keeps the K candidate poses in LDS; workgroup 0 also stores them) --------------------------------------
+        {
+            for (int k = tid; k < K; k += BA_THREADS) {
+                bg_apply_update(a.dp + (size_t)k * 6, T + (size_t)k * 12, sTn + (size_t)k * 12);
+                if (blk == 0)
+                    for (int x = 0; x < 12; x++) Tn[(size_t)k * 12 + x] = sTn[(size_t)k * 12 + x];
+            }
+            __syncthreads();
+            double sc = 0.0, cc = 0.0;
+            for (int b = blk; b * BA_THREADS < L; b += G) {
+                ba_backsub_body(a.pt_ptr, a.pt_obs, a.obs_pose, L, a.rec, a.E, a.bl, a.dp, a.dl, b);
+                const int l = b * BA_THREADS + tid;
+                if (l < L) {
+                    double p[3];
+#pragma unroll
+                    for (int x = 0; x < 3; x++) {
+                        const double d = a.dl[(size_t)l * 3 + x];          // this thread's own store
+                        p[x] = X[(size_t)l * 3 + x] + d;
+                        Xn[(size_t)l * 3 + x] = p[x];
+                        sc += d * (lam * d - a.bl[(size_t)l * 3 + x]);
+                    }
+                    for (int i = a.pt_ptr[l]; i < a.pt_ptr[l + 1]; i++) {
+                        const int o = a.pt_obs[i];
+                        const double* P = sTn + (size_t)a.obs_pose[o] * 12;
+                        const double Xc = P[0] * p[0] + P[1] * p[1] + P[2] * p[2] + P[3];
+                        const double Yc = P[4] * p[0] + P[5] * p[1] + P[6] * p[2] + P[7];
+                        const double Zc = P[8] * p[0] + P[9] * p[1] + P[10] * p[2] + P[11];
+                        const double2 m = a.meas[o];
+                        const double e0 = m.x - (a.cam.fx * Xc + a.cam.cx * Zc) / Zc;
+                        const double e1 = m.y - (a.cam.fy * Yc + a.cam.cy * Zc) / Zc;
+                        const double c2 = e0 * e0 + e1 * e1;
+                        double rho = c2;
+                        if (a.delta > 0.0) {
+                            const double en = sqrt(c2);
+                            if (en > a.delta) rho = 2.0 * a.delta * en - a.delta * a.delta;
+                        }
+                        cc += rho;
+                    }
+                }
+            }
+            if (blk == 0)
+                for (int k = tid; k < K; k += BA_THREADS)
+                    for (int x = 0; x < 6; x++) sc += a.dp[(size_t)k * 6 + x] * (lam * a.dp[(size_t)k * 6 + x] - a.bp[(size_t)k * 6 + x]);
+            double acc[2] = {sc, cc};
+            ba_block_sum<2>(acc, (double(*)[2])sw, out);
+            if (tid == 0) { a.part[2 * blk] = out[0]; a.part[2 * blk + 1] = out[1]; }
+        }
+        if (!bg_grid_sync(c, G, gen)) return;
+        // ---- verdict (replicated) ------------------------------------------------------------------------------------------------------
+        {
+            double scale = 1e-3, cc = 0.0;
+            for (int b = 0; b < G; b++) { scale += a.part[2 * b]; cc += a.part[2 * b + 1]; }
+            const double rho = (cost - cc) / scale;
+            trials++;
+            if (rho > 0.0 && isfinite(cc)) {
+                cur = 1 - cur;                             // the candidate buffers become the state
+                cost = cc;
+                need_lin = 1;
+                const double g = 2.0 * rho - 1.0;
+                lambda = lam * fmax(1.0 / 3.0, fmin(1.0 - g * g * g, 2.0 / 3.0));
+                ni = 2.0;
+                accepted++; iter++; trial = 0;
+                if (iter >= a.iterations) done = 1;
+            } else {
+                lambda = lam * ni;
+                ni *= 2.0;
+                trial++;
+                if (trial >= 10 || !isfinite(lambda)) done = 1;   // an iteration without an accepted step ends the run
+            }
+        }
+    }
+    if (blk == 0 && tid == 0) {
+        a.stats[1] = cost;
+        a.stats[2] = (double)accepted;
+        a.stats[3] = (double)trials;
+        a.stats[4] = lambda;
+        a.stats[5] = (double)bg_load(&c->abort);
+        a.stats[6] = (double)cur;
+        a.stats[7] = (double)G;
+    }
+}
+
+static inline uint64_t bg_round16(uint64_t b) { return (b + 15) / 16 * 16; }
+
+// number of workgroups of the persistent launch: enough for one task each in the widest phase, at most 128
+static int bg_blocks(int64_t K, int64_t L, int64_t O, int64_t n_free) {
+    int64_t want = K + n_free * (n_free + 1) / 2;
+    if ((O + BA_THREADS - 1) / BA_THREADS > want) want = (O + BA_THREADS - 1) / BA_THREADS;
+    if ((L + BA_THREADS - 1) / BA_THREADS > want) want = (L + BA_THREADS - 1) / BA_THREADS;
+    return (int)(want < 8 ? 8 : (want > 128 ? 128 : want));
+}
+
+extern "C" int slam_ba_optimize_workspace(int64_t K, int64_t L, int64_t O, uint64_t* bytes) {
+    SLAM_REQUIRE(bytes, "slam_ba_optimize_workspace: null pointer");
+    SLAM_REQUIRE(K >= 1 && K <= 64 && L >= 1 && L <= (1 << 24) && O >= 0 && O <= SLAM_BA_LM_MAX_OBS, "bad sizes");
+    *bytes = bg_round16(sizeof(bg_ctl)) + bg_round16((uint64_t)K * L * 4) + bg_round16((uint64_t)(O ? O : 1) * BA_REC * 8) +
+             bg_round16((uint64_t)L * 72) + 2 * bg_round16((uint64_t)L * 24) + bg_round16((uint64_t)K * 168) + 2 * bg_round16((uint64_t)K * 48) +
+             2 * bg_round16((uint64_t)K * 8) + bg_round16((uint64_t)K * K * 288) + bg_round16((uint64_t)K * 48) + bg_round16((uint64_t)L * 24) +
+             bg_round16(2 * 128 * 8);
+    return SLAM_OK;
+}
+
+extern "C" int slam_ba_optimize_f64(slam_ctx* ctx, int64_t K, int64_t L, int64_t O, const int32_t* d_obs_pose,
+                                    const int32_t* d_obs_point, const double* d_meas, const int32_t* d_pt_ptr,
+                                    const int32_t* d_pt_obs, const int32_t* d_ps_ptr, const int32_t* d_ps_obs,
+                                    const int32_t* d_free_poses, int64_t n_free, double fx, double fy, double cx, double cy,
+                                    double huber_delta, int iterations, double* d_poses2, double* d_points2, void* d_work,
+                                    uint64_t work_bytes, double* d_stats) {
+    SLAM_REQUIRE(ctx, "slam_ba_optimize_f64: null ctx");
+    SLAM_REQUIRE(K >= 1 && K <= 64 && L >= 1 && L <= (1 << 24) && O >= 0 && O <= SLAM_BA_LM_MAX_OBS, "bad sizes (K=%lld, L=%lld, O=%lld)",
+                 (long long)K, (long long)L, (long long)O);
+    SLAM_REQUIRE(n_free >= 0 && n_free <= SLAM_BA_LM_MAX_FREE && n_free <= K, "n_free=%lld: at most %d free poses", (long long)n_free,
+                 SLAM_BA_LM_MAX_FREE);
+    SLAM_REQUIRE(iterations >= 0 && iterations <= 1000, "bad iteration count");
+    SLAM_REQUIRE(d_obs_pose && d_obs_point && d_meas && d_pt_ptr && d_pt_obs && d_ps_ptr && d_ps_obs && (d_free_poses || n_free == 0) &&
+                     d_poses2 && d_points2 && d_work && d_stats, "slam_ba_optimize_f64: null device pointer");
+    SLAM_REQUIRE(((uintptr_t)d_meas & 15) == 0 && ((uintptr_t)d_work & 15) == 0, "d_meas and d_work must be 16-byte aligned");
+    uint64_t need = 0;
+    if (int rc = slam_ba_optimize_workspace(K, L, O, &need)) return rc;
+    SLAM_REQUIRE(work_bytes >= need, "workspace of %llu bytes, %llu needed (slam_ba_optimize_workspace)", (unsigned long long)work_bytes,
+                 (unsigned long long)need);
+    SLAM_HIP(hipSetDevice(ctx->device));
+    bg_args a;
+    a.K = (int)K; a.L = (int)L; a.O = (int)O; a.iterations = iterations; a.nfree = (int)n_free;
+    a.nblocks = bg_blocks(K, L, O, n_free);
+    a.obs_pose = d_obs_pose; a.obs_point = d_obs_point; a.meas = (const double2*)d_meas;
+    a.pt_ptr = d_pt_ptr; a.pt_obs = d_pt_obs; a.ps_ptr = d_ps_ptr; a.ps_obs = d_ps_obs; a.free_list = d_free_poses;
+    a.T = d_poses2; a.X = d_points2;
+    char* w = (char*)d_work;
+    auto take = [&](uint64_t bytes) { char* p = w; w += bg_round16(bytes); return p; };
+    a.ctl = (bg_ctl*)take(sizeof(bg_ctl));
+    a.lookup = (int*)take((uint64_t)K * L * 4);
+    a.rec = (double*)take((uint64_t)(O ? O : 1) * BA_REC * 8);
+    a.E = (double*)take((uint64_t)L * 72); a.bl = (double*)take((uint64_t)L * 24); a.hll = (double*)take((uint64_t)L * 24);
+    a.Hpp = (double*)take((uint64_t)K * 168); a.bp = (double*)take((uint64_t)K * 48); a.ybl = (double*)take((uint64_t)K * 48);
+    a.costk = (double*)take((uint64_t)K * 8); a.costn = (double*)take((uint64_t)K * 8);
+    a.W = (double*)take((uint64_t)K * K * 288);
+    a.dp = (double*)take((uint64_t)K * 48); a.dl = (double*)take((uint64_t)L * 24);
+    a.part = (double*)take(2 * 128 * 8);
+    a.stats = d_stats;
+    a.index_errors = slam_index_error_counter(ctx);
+    a.cam = {fx, fy, cx, cy};
+    a.delta = huber_delta;
+    // the control block starts as: barrier idle, no abort, state in half 0
+    SLAM_HIP(hipMemsetAsync(a.ctl, 0, sizeof(bg_ctl), ctx->stream));                           // (workgroup 0 fills in the rest before the first barrier)
+    SLAM_HIP(hipMemsetAsync(d_stats, 0xFF, 64, ctx->stream));                                  // all-NaN until the launch completes
+    ba_lm_grid_kernel<<<(unsigned)a.nblocks, BA_THREADS, 0, ctx->stream>>>(a);
     SLAM_HIP(hipGetLastError());
     return SLAM_OK;
 }

@@ -225,9 +225,12 @@ class SchurProblem:
                                               self.d_rec.ptr, self.d_E.ptr, self.d_bl.ptr, self.d_dp.ptr, self.d_dl.ptr))
         return self.d_dl.download(np.float64, (self.L, 3)), self.d_bl.download(np.float64, (self.L, 3))
 
-    def diag_max(self) -> float:
-        """Largest diagonal entry of Hpp / Hll of the last ``reduce`` (g2o-style initial damping)."""
+    def diag_max(self, free=None) -> float:
+        """Largest diagonal entry of the Hpp blocks of the poses ``free`` (all if None) and of every Hll of the last
+        ``reduce`` (g2o-style initial damping; poses that hold the gauge are not part of the system)."""
         tri = self.d_Hpp.download(np.float64, (self.K, 21))
+        if free is not None:
+            tri = tri[np.asarray(free, np.int64)]
         d = tri[:, [0, 6, 11, 15, 18, 20]].max(initial=0.0)
         if self.O:
             d = max(d, self.d_hll.download(np.float64, (self.L, 3)).max(initial=0.0))
@@ -238,6 +241,78 @@ class SchurProblem:
             if name.startswith("d_") and b is not None:
                 b.free()
                 setattr(self, name, None)
+
+
+# the single-launch form (slam_ba_optimize_f64) takes windows of up to 16 free poses (a 96 x 96 reduced system in LDS),
+# 64 poses and 131072 observations; measured (tools/ba_time.py) it is ahead of the multi-launch form at K = 7 (1.0 vs 2.9 ms
+# for five steps) and at K = 16 / 48 k observations (3.3 vs 5.4 ms)
+ONE_LAUNCH_MAX_FREE, ONE_LAUNCH_MAX_OBS = 16, 131072
+
+
+def bundle_adjust_one_launch(poses, points, obs_pose_idx, obs_point_idx, meas, intrinsics, iterations: int = 10,
+                             fixed_poses: Sequence[int] = (0,), huber_delta: float = 0.0,
+                             ctx: Optional[Context] = None) -> BAResult:
+    """``bundle_adjust_device`` with the whole Levenberg-Marquardt loop in ONE kernel launch (``slam_ba_optimize_f64``):
+    the window goes up once, the dense reduced system is solved on the device, the trials, their costs and the accept /
+    reject decisions never leave it, the result comes back once.  For windows of at most 16 moving poses (the reference
+    keeps 7 keyframes, ``backend.py:11``)."""
+    import ctypes
+
+    ctx = ctx or default_context()
+    P = np.asarray(poses, np.float64)
+    T = np.tile(np.eye(4), (P.shape[0], 1, 1))
+    T[:, :3, :4] = (P.reshape(-1, 12) if P.ndim == 2 else poses_to_rt12(P)).reshape(-1, 3, 4)
+    X = np.array(points, np.float64).reshape(-1, 3)
+    K, L = T.shape[0], X.shape[0]
+    op = np.ascontiguousarray(obs_pose_idx, np.int32).reshape(-1)
+    ol = np.ascontiguousarray(obs_point_idx, np.int32).reshape(-1)
+    meas = np.ascontiguousarray(meas, np.float64).reshape(-1, 2)
+    O = op.shape[0]
+    if ol.shape[0] != O or meas.shape[0] != O:
+        raise ValueError("obs_pose, obs_point and meas must have one row per observation")
+    if K < 1 or L < 1:
+        raise ValueError("need at least one pose and one point")
+    if O and (op.min() < 0 or op.max() >= K or ol.min() < 0 or ol.max() >= L):
+        raise ValueError("observation index out of range")
+    if O and np.unique(op.astype(np.int64) * L + ol).size != O:
+        raise ValueError("a (pose, point) pair is observed more than once")
+    free = np.ones(K, bool)
+    free[list(fixed_poses)] = False
+    fidx = np.flatnonzero(free).astype(np.int32)
+    pt_obs = np.argsort(ol, kind="stable").astype(np.int32)
+    ps_obs = np.argsort(op, kind="stable").astype(np.int32)
+    pt_ptr = np.zeros(L + 1, np.int32); pt_ptr[1:] = np.cumsum(np.bincount(ol, minlength=L))
+    ps_ptr = np.zeros(K + 1, np.int32); ps_ptr[1:] = np.cumsum(np.bincount(op, minlength=K))
+    # one upload: every table and the state packed into one block (offsets in bytes, 16-byte aligned)
+    parts = [op, ol, meas if O else np.zeros((1, 2)), pt_ptr, pt_obs, ps_ptr, ps_obs, fidx,
+             np.concatenate([T[:, :3, :4].reshape(-1), np.zeros(K * 12)]), np.concatenate([X.reshape(-1), np.zeros(L * 3)])]
+    offs, blob = [], bytearray()
+    for a in parts:
+        raw = np.ascontiguousarray(a).tobytes() or bytes(16)       # an empty table still gets an address
+        offs.append(len(blob))
+        blob += raw + bytes((-len(raw)) % 16)
+    need = ctypes.c_uint64(0)
+    check(ctx.lib.slam_ba_optimize_workspace(K, L, O, ctypes.byref(need)))
+    fx, fy, cx, cy = (float(v) for v in intrinsics)
+    d_in = ctx.upload(np.frombuffer(bytes(blob), np.uint8))
+    d_work, d_stats = ctx.malloc(need.value), ctx.malloc(64)
+    try:
+        ptr = lambda i: d_in.ptr + offs[i]
+        check(ctx.lib.slam_ba_optimize_f64(ctx.handle, K, L, O, ptr(0), ptr(1), ptr(2), ptr(3), ptr(4), ptr(5), ptr(6), ptr(7),
+                                           len(fidx), fx, fy, cx, cy, float(huber_delta), int(iterations), ptr(8), ptr(9),
+                                           d_work.ptr, need.value, d_stats.ptr))
+        st = d_stats.download(np.float64, (8,))
+        if not np.isfinite(st[:7]).all() or st[5] != 0:
+            raise RuntimeError("slam_ba_optimize_f64 did not complete (its grid barrier was abandoned); stats = %r" % (st.tolist(),))
+        half = int(st[6])
+        Tout = d_in.view(offs[8] + half * K * 96, K * 96).download(np.float64, (K, 3, 4))
+        Xout = d_in.view(offs[9] + half * L * 24, L * 24).download(np.float64, (L, 3))
+    finally:
+        for b in (d_in, d_work, d_stats):
+            b.free()
+    Tr = np.tile(np.eye(4), (K, 1, 1))
+    Tr[:, :3, :4] = Tout
+    return BAResult(poses=Tr, points=Xout, chi2_initial=float(st[0]), chi2_final=float(st[1]), iterations=int(st[2]))
 
 
 def bundle_adjust_device(poses, points, obs_pose_idx, obs_point_idx, meas, intrinsics, iterations: int = 10,
@@ -260,7 +335,7 @@ def bundle_adjust_device(poses, points, obs_pose_idx, obs_point_idx, meas, intri
     try:
         S, rhs, bp, cost = prob.reduce(rt(T), X, huber_delta, 1.0)
         cost0 = cost
-        lam = 1e-5 * max(prob.diag_max(), 1e-12)
+        lam = 1e-5 * max(prob.diag_max(fidx), 1e-12)
         ni, accepted = 2.0, 0
         for _ in range(iterations):
             step_ok = False

@@ -421,3 +421,59 @@ def test_batched_pose_refinement_equals_one_frame_at_a_time_and_the_oracle(gpu_c
         else:
             assert np.allclose(batch[b].pose, poses[b]) and batch[b].n_inliers == 0
     assert be.optimize_poses(np.zeros((0, 4, 4)), [], [], FX, FY, CX, CY) == []
+
+
+@pytest.mark.parametrize("K,L,delta,fixed,density", [(7, 300, 0.0, (0, 1), 0.6), (7, 1400, 1.0, (0, 1), 0.6), (3, 40, 1.5, (0,), 0.9),
+                                                       (17, 200, 0.0, (0,), 0.5), (5, 60, 0.0, (0, 1, 2, 3, 4), 0.8)])
+def test_one_launch_ba_follows_the_oracle_trajectory(gpu_ctx, K, L, delta, fixed, density):
+    """slam_ba_optimize_f64 (the whole window LM in one launch: linearisation, Schur complement, dense LDL^T solve in
+    LDS, exp update, cost, accept / reject on the device) against oracle.ba_lm_np, the CPU loop over the C oracle's
+    residuals and Jacobians: the same number of accepted steps, the same final cost (1e-9 relative), poses to 1e-8,
+    points to 1e-7; and against the host-driven device form (slam_ba_reduce_f64 + numpy solve).  Cases: the reference's
+    window of 7 keyframes with and without the Huber kernel, a tiny window, 16 free poses (the 96 x 96 system: the
+    largest the form takes), and a window whose every pose is fixed (nothing to solve: the state comes back unchanged)."""
+    from oracle import oracle
+    from slamhip.ba import bundle_adjust_device, bundle_adjust_one_launch
+
+    rng = np.random.default_rng(1000 * K + L)
+    T, X, op, ol, meas = _window(rng, K, L, density)
+    moving = [k for k in range(K) if k not in fixed]
+    T0 = T.copy()
+    for k in moving:
+        T0[k] = oracle.se3_exp_np(rng.normal(0, 0.01, 6)) @ T[k]
+    X0 = X + rng.normal(0, 0.05, X.shape)
+    iters = 6
+    got = bundle_adjust_one_launch(T0, X0, op, ol, meas, (FX, FY, CX, CY), iterations=iters, fixed_poses=fixed, huber_delta=delta, ctx=gpu_ctx)
+    again = bundle_adjust_one_launch(T0, X0, op, ol, meas, (FX, FY, CX, CY), iterations=iters, fixed_poses=fixed, huber_delta=delta, ctx=gpu_ctx)
+    assert np.array_equal(got.poses, again.poses) and np.array_equal(got.points, again.points) and got.chi2_final == again.chi2_final
+    Tr, Xr, c0, c1, acc, lams = oracle.ba_lm_np(T0[:, :3, :4].reshape(K, 12), X0, op, ol, meas, FX, FY, CX, CY, iters, fixed, delta)
+    assert abs(got.chi2_initial - c0) <= 1e-9 * c0
+    assert got.iterations == acc, (got.iterations, acc)
+    assert abs(got.chi2_final - c1) <= 1e-9 * max(c1, 1.0), (got.chi2_final, c1)
+    assert np.abs(got.poses - Tr).max() <= 1e-8 and np.abs(got.points - Xr).max() <= 1e-7
+    for k in fixed:
+        assert np.array_equal(got.poses[k], T0[k])
+    if moving:
+        assert acc >= 3 and c1 < 0.05 * c0
+        dev = bundle_adjust_device(T0, X0, op, ol, meas, (FX, FY, CX, CY), iterations=iters, fixed_poses=fixed, huber_delta=delta, ctx=gpu_ctx)
+        assert dev.iterations == got.iterations and abs(dev.chi2_final - got.chi2_final) <= 1e-9 * max(c1, 1.0)
+        assert np.abs(dev.poses - got.poses).max() <= 1e-8
+    else:
+        assert acc == 0 and np.array_equal(got.poses, T0) and np.array_equal(got.points, X0)
+
+
+def test_one_launch_ba_limits_are_reported(gpu_ctx):
+    import ctypes
+
+    lib, ctx = gpu_ctx.lib, gpu_ctx
+    need = ctypes.c_uint64(0)
+    assert lib.slam_ba_optimize_workspace(7, 1400, 6000, ctypes.byref(need)) == 0 and need.value > 7 * 1400 * 4
+    assert lib.slam_ba_optimize_workspace(65, 10, 10, ctypes.byref(need)) == -1           # more than 64 poses
+    assert lib.slam_ba_optimize_workspace(7, 10, (1 << 17) + 1, ctypes.byref(need)) == -1  # more observations than one CU should take
+    buf = ctx.malloc(4096)
+    args = [buf.ptr] * 7
+    assert lib.slam_ba_optimize_f64(ctx.handle, 20, 10, 10, *args, buf.ptr, 17, FX, FY, CX, CY, 0.0, 5, buf.ptr, buf.ptr, buf.ptr, 4096, buf.ptr) == -1
+    assert b"at most 16 free poses" in lib.slam_last_error()
+    assert lib.slam_ba_optimize_f64(ctx.handle, 7, 1400, 6000, *args, buf.ptr, 5, FX, FY, CX, CY, 0.0, 5, buf.ptr, buf.ptr, buf.ptr, 4096, buf.ptr) == -1
+    assert b"workspace" in lib.slam_last_error()
+    buf.free()
