@@ -553,9 +553,12 @@ static void plan_uniform(const slam_ctx* ctx, int64_t N, int64_t M, int R, int b
     p->qblocks = (int)((N + 256 * R - 1) / (256 * R));
     if (qb_all < p->qblocks) qb_all = p->qblocks;
     // 32 blocks per CU = 4 rounds at 8 waves/SIMD: finished waves keep being replaced, so the
-    // under-occupied tail (a lone wave per SIMD issues at under half rate) is short; query shards
-    // with fewer query blocks than CUs (multi-GPU runs) measured 3-5 % faster still with 64.
-    if (!blocks_per_cu) blocks_per_cu = p->qblocks >= ctx->num_cu ? 32 : 64;
+    // under-occupied tail (a lone wave per SIMD issues at under half rate) is short.  Query shards
+    // with fewer query blocks than CUs (multi-GPU runs) want FEWER, longer chunks since the train rows
+    // travel through SGPRs from 512 rows per chunk up (round 2's LDS-only kernel preferred 64 here):
+    // 24 measured best over 8192 / 16384 / 32768 x 65536 and 8192 x 2^20 (profiles/r03_shard_plan_sweep.log:
+    // the 1/8 shard of the 64k x 64k grid 187 -> 174 us, 16384 x 65536 334 -> 296 us).
+    if (!blocks_per_cu) blocks_per_cu = p->qblocks >= ctx->num_cu ? 32 : 24;
     int64_t S = (int64_t)ctx->num_cu * blocks_per_cu / qb_all;
     if (S > tiles) S = tiles;
     if (S < 1) S = 1;

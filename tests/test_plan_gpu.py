@@ -63,7 +63,8 @@ def test_plan_tables_and_degenerate_inputs(gpu_ctx):
         ctx.set_tuning()
     # the feed follows the chunk length: SGPRs from 512 rows per chunk up, the LDS tile below (and for frame-sized calls)
     assert ctx.plan_info(65536, 65536)["sgpr_feed"] == 1 and ctx.plan_info(1 << 20, 1 << 20)["sgpr_feed"] == 1
-    assert ctx.plan_info(20000, 20000)["sgpr_feed"] == 0 and ctx.plan_info(200, 200)["sgpr_feed"] == 0
+    assert ctx.plan_info(65536, 4096)["sgpr_feed"] == 1 and ctx.plan_info(8192, 65536)["sgpr_feed"] == 1
+    assert ctx.plan_info(4096, 4096)["sgpr_feed"] == 0 and ctx.plan_info(200, 200)["sgpr_feed"] == 0
     n, m = 700, 20000
     rng = np.random.default_rng(3)
     q = rng.integers(0, 256, (n, 32), dtype=np.uint8)

@@ -1,9 +1,9 @@
-"""Summarise the two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) over bench.py into profiles/r02_hbm_counters.json.
+"""Summarise the two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) over bench.py into profiles/hbm_counters.json.
 
-Usage (on the GPU box, each pass on its own as MI355X_MICROARCH.md prescribes; tools/profile_r02.sh does all of it):
+Usage (on the GPU box, each pass on its own as MI355X_MICROARCH.md prescribes; tools/profile.sh does all of it):
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o fetch -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o write -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline
-  python tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write > profiles/r02_hbm_counters.json
+  python tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write > profiles/hbm_counters.json
 
 The summary is stamped with the hash of the kernel sources it was collected on; bench.py prints `traffic: null` with
 the reason when a stamp no longer matches the source in the tree.

@@ -1,9 +1,9 @@
-"""Summarise rocprofv3 --pmc passes of SQ counters over bench.py for the top-2 kernel (-> profiles/r02_sq_counters.json).
+"""Summarise rocprofv3 --pmc passes of SQ counters over bench.py for the top-2 kernel (-> profiles/<round>_sq_counters.json).
 
-    python tools/sq_summary.py DIR [DIR ...] > profiles/r02_sq_counters.json
+    python tools/sq_summary.py DIR [DIR ...] > profiles/<round>_sq_counters.json
 
 Each DIR is the output directory of one pass (the counters of one pass must fit the SQ's counter slots; see
-tools/profile_r02.sh for the passes)."""
+tools/profile.sh for the passes)."""
 import csv, glob, hashlib, json, os, statistics, sys
 from collections import defaultdict
 
@@ -24,16 +24,20 @@ for d in sys.argv[1:]:
         for name, v in per.items():
             raw[name] = {"median": statistics.median(v), "launches": len(v)}
 wave_rows = N * M / 64.0
-with open(os.path.join(ROOT, "slam-experiments_amd", "csrc", "bf_hamming.hip"), "rb") as f:
-    sha = hashlib.sha256(f.read()).hexdigest()[:16]
-out = {"kernel": f"bf_top2_kernel<1>, {N} x {M}, medians over the launches of the profiled command",
-       "source_sha": {"bf_hamming.hip": sha}, "wave_rows_per_launch": wave_rows, "per_wave_row": {}, "raw": raw}
+def _sha(name):
+    with open(os.path.join(ROOT, "slam-experiments_amd", "csrc", name), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+out = {"kernel": f"bf_top2_kernel, {N} x {M}, medians over the launches of the profiled command",
+       "source_sha": {n: _sha(n) for n in ("bf_hamming.hip", "bf_scan_sgpr.h")}, "wave_rows_per_launch": wave_rows, "per_wave_row": {}, "raw": raw}
 for key, name in (("valu_instructions", "SQ_INSTS_VALU"), ("salu_instructions", "SQ_INSTS_SALU"), ("lds_instructions", "SQ_INSTS_LDS"),
-                  ("vmem_read_instructions", "SQ_INSTS_VMEM_RD"), ("vmem_write_instructions", "SQ_INSTS_VMEM_WR")):
+                  ("smem_instructions", "SQ_INSTS_SMEM"), ("vmem_read_instructions", "SQ_INSTS_VMEM_RD"),
+                  ("vmem_write_instructions", "SQ_INSTS_VMEM_WR")):
     if name in raw:
         out["per_wave_row"][key] = raw[name]["median"] / wave_rows
 if "SQ_WAVES" in raw:
     out["waves_per_launch"] = raw["SQ_WAVES"]["median"]
+if "GRBM_GUI_ACTIVE" in raw:
+    out["grbm_gui_active_per_launch_sum_over_8_xcds"] = raw["GRBM_GUI_ACTIVE"]["median"]
 if "SQ_WAVE_CYCLES" in raw and "SQ_WAIT_INST_ANY" in raw:
     out["wait_inst_any_share_of_wave_cycles"] = raw["SQ_WAIT_INST_ANY"]["median"] / raw["SQ_WAVE_CYCLES"]["median"]
 print(json.dumps(out, indent=1))
