@@ -20,15 +20,16 @@ OBJS=$(ls "$ROOT"/slam-experiments_amd/lib/obj/*.o | grep -v bf_hamming)
 python3 - "$SRC/bf_hamming.hip" "$TMP/bf_trace.hip" "$TMP/bf_keep.hip" "$TMP/bf_count.hip" "$TMP/bf_cycles.hip" <<'EOF'
 import sys
 src = open(sys.argv[1]).read()
-T = '    if (tid == 0 && g_trace) { g_trace[4*(blockIdx.y*gridDim.x+blockIdx.x)+%d] = wall_clock64(); }\n'
-s = src.replace('    const bool leader = (int)blockIdx.y < lead;\n', T % 0 + '    const bool leader = (int)blockIdx.y < lead;\n', 1)
-s = s.replace('    int buf = 0;\n', T % 1 + '    int buf = 0;\n', 1)
+T = '    if (tid == 0 && g_trace) { g_trace[4*(by*(int)gridDim.x+bx)+%d] = wall_clock64(); }\n'
+s = src.replace('    const bool leader = by < lead;\n', T % 0 + '    const bool leader = by < lead;\n', 1)
+s = s.replace('        int buf = 0;\n', '    ' + T % 1 + '        int buf = 0;\n', 1)
+s = s.replace('        int row = t0;\n', '    ' + T % 1 + '        int row = t0;\n', 1)
 s = s.replace('    // ---- epilogue: merge,', T % 2 + '    // ---- epilogue: merge,', 1)
 s = s.replace('    if (!s_last) return;\n', T % 3 + '    if (!s_last) return;\n', 1)
 s = s.replace('typedef uint32_t u32;', 'typedef uint32_t u32;\n__device__ unsigned long long* g_trace = nullptr;\n'
               'extern "C" __attribute__((visibility("default"))) int slam_exp_set_trace(void* p) '
               '{ return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &p, sizeof(p)); }', 1)
-assert s.count('g_trace[') == 4, "trace hooks did not apply: the kernel source changed"
+assert s.count('g_trace[') == 5, "trace hooks did not apply: the kernel source changed"
 open(sys.argv[2], 'w').write(s)
 old = '__hip_atomic_store(&st.bound[qi], 0x7F7F7F7Fu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);'
 assert src.count(old) == 1, "keep-bound hook did not apply: the kernel source changed"
@@ -45,15 +46,16 @@ c = c.replace('typedef uint32_t u32;', 'typedef uint32_t u32;\n__device__ unsign
 open(sys.argv[4], 'w').write(c)
 # cycle stamps: one asm statement per stamp (s_memtime + s_memrealtime + the wait), wave 0 lane 0 stores both
 C = ('    if (g_cyc) { unsigned long long c_, r_; asm volatile("s_memtime %%0\\n\\ts_memrealtime %%1\\n\\ts_waitcnt lgkmcnt(0)" : "=s"(c_), "=s"(r_) :: "memory");\n'
-     '        if (tid == 0) { g_cyc[8*(blockIdx.y*gridDim.x+blockIdx.x)+%d] = c_; g_cyc[8*(blockIdx.y*gridDim.x+blockIdx.x)+%d] = r_; } }\n')
-y = src.replace('    const bool leader = (int)blockIdx.y < lead;\n', C % (0, 1) + '    const bool leader = (int)blockIdx.y < lead;\n', 1)
-y = y.replace('    int buf = 0;\n', C % (2, 3) + '    int buf = 0;\n', 1)
+     '        if (tid == 0) { g_cyc[8*(by*(int)gridDim.x+bx)+%d] = c_; g_cyc[8*(by*(int)gridDim.x+bx)+%d] = r_; } }\n')
+y = src.replace('    const bool leader = by < lead;\n', C % (0, 1) + '    const bool leader = by < lead;\n', 1)
+y = y.replace('        int buf = 0;\n', C % (2, 3) + '        int buf = 0;\n', 1)
+y = y.replace('        int row = t0;\n', C % (2, 3) + '        int row = t0;\n', 1)
 y = y.replace('    // ---- epilogue: merge,', C % (4, 5) + '    // ---- epilogue: merge,', 1)
 y = y.replace('    if (!s_last) return;\n', C % (6, 7) + '    if (!s_last) return;\n', 1)
 y = y.replace('typedef uint32_t u32;', 'typedef uint32_t u32;\n__device__ unsigned long long* g_cyc = nullptr;\n'
               'extern "C" __attribute__((visibility("default"))) int slam_exp_set_cycles(void* p) '
               '{ return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_cyc), &p, sizeof(p)); }', 1)
-assert y.count('g_cyc[') == 8, "cycle hooks did not apply: the kernel source changed"
+assert y.count('g_cyc[') == 10, "cycle hooks did not apply: the kernel source changed"
 open(sys.argv[5], 'w').write(y)
 EOF
 for v in trace keep count cycles; do

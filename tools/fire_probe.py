@@ -25,7 +25,8 @@ for n, m in sizes:
     q = slamhip.DeviceDescriptors(ctx, np.random.default_rng(228).integers(0, 256, (n, 32), dtype=np.uint8))
     t = slamhip.DeviceDescriptors(ctx, np.random.default_rng(229).integers(0, 256, (m, 32), dtype=np.uint8))
     tab = slamhip.Top2Table(ctx, n)
-    for label, kw in (("shipped plan", {}), ("no leaders, no tail (round-1 plan)", {"lead_rows": -1, "tail": -1})):
+    # the counters sit in the C++ (LDS-tile) form of the scan; the SGPR-fed form runs the same filter with the same thresholds
+    for label, kw in (("shipped plan (LDS-tile form forced)", {"feed": -1}), ("no leaders, no tail (round-1 plan)", {"lead_rows": -1, "tail": -1, "feed": -1})):
         ctx.set_tuning(**kw)
         for _ in range(3):
             slamhip.knn2_device(ctx, q.buf, n, t.buf, m, tab.idx, tab.dist)
