@@ -6,44 +6,44 @@
 //   * lane <-> query: every lane keeps R query descriptors in registers
 //     (8*R VGPRs), so the per-query top-2 lives in registers and never needs a
 //     cross-lane reduction.
-//   * train rows are staged global -> LDS with coalesced 16-B loads (one
-//     256-row / 8-KiB tile per step, double buffered) and read back as
-//     wave-uniform (broadcast) ds_read_b128, so one LDS read feeds 64*R pairs.
 //   * inner op per 32-bit word: v_xor_b32 + accumulating v_bcnt_u32_b32 =
-//     16 VALU ops per 256-bit pair, the floor for this ISA without MFMA.
+//     16 VALU ops per 256-bit pair, the floor for this ISA without MFMA.  A
+//     gfx950 SIMD runs two wave64 VALU instructions at once when they come from
+//     different waves and at most one of them is a v_bcnt, so the floor is
+//     16 x 4 / 2 = 32 cycles per wave-row; the wave raises its priority for its
+//     v_bcnt half so that the v_bcnt of one wave pairs with the v_xor of another
+//     (row_acc below; measured in shader cycles by tools/ubench/cycles.hip).
+//   * train rows are wave-uniform.  Long chunks (>= 512 rows) stream them through
+//     SGPRs: s_load_dwordx16 + v_xor with the SGPR operand, no LDS, no barrier
+//     (bf_scan_sgpr.h, one generated asm statement per stretch of rows).  Short
+//     chunks and frame-sized calls stage them global -> LDS with coalesced 16-B
+//     loads (one 256-row / 8-KiB tile per step, double buffered) and read them
+//     back as wave-uniform (broadcast) ds_read_b128.
 //   * top-2 maintenance is filtered: each accumulator starts at
 //     2^31 - (current threshold), so "this pair improved" is the sign bit of
 //     the accumulator.  The accumulators of 16 consecutive train rows are
-//     AND-ed (v_and is a 2-cycle op; v_min / v_cmp are 4) and one compare + one
-//     wave-uniform branch on the ballot (update block laid out as unlikely)
-//     serves the whole group.  The update itself is branch-free on packed keys
-//     (dist << 23 | train index): 2nd = med3, 1st = min, which keeps OpenCV's
-//     (distance asc, index asc) order because keys are unique and compare
-//     lexicographically.
+//     combined (AND tree in the LDS form, unsigned min3 chain in the SGPR form)
+//     and one compare + one wave-uniform branch on the ballot (update block laid
+//     out as unlikely) serves the whole group.  The update itself is branch-free
+//     on packed keys (dist << 23 | train index): 2nd = med3, 1st = min, which
+//     keeps OpenCV's (distance asc, index asc) order because keys are unique and
+//     compare lexicographically.
 //   * the train axis is split into chunks (grid.y) so any N fills 256 CUs and
-//     finished waves are replaced until the end (a lone wave per SIMD issues at
-//     under half rate).  Chunk boundaries come from a small table built on the
-//     host: a few short LEADER chunks first, then uniform ones, then a run of
-//     shrinking ones so that the blocks dispatched last have the least to do.
-//     Blocks that scan different chunks for the same queries exchange their
-//     2nd-best distance through a per-query bound in global memory (atomicMin +
-//     relaxed agent-scope load per tile, more often in a block's first tile), so
-//     a chunk does not start from an infinite threshold; a stale bound is only
-//     looser, never wrong.  The leader blocks (lowest grid.y, dispatched first,
-//     hence the oldest waves, which the age-ordered VALU arbiter serves first)
-//     are short and publish the exact 2nd-best distance over their rows, so the
-//     rest of the grid gets a tight bound early.
+//     finished waves are replaced until the end.  Chunk boundaries come from a
+//     small table built on the host: leader chunk(s) first, then uniform ones,
+//     then a run of shrinking ones so that the blocks dispatched last have the
+//     least to do.  Blocks that scan different chunks for the same queries
+//     exchange their 2nd-best distance through a per-query bound in global
+//     memory (atomicMin + relaxed agent-scope load per 256 rows, more often in a
+//     block's first rows), so a chunk does not start from an infinite threshold;
+//     a stale bound is only looser, never wrong.  The leader blocks (lowest
+//     grid.y, dispatched first) publish the exact 2nd-best distance of
+//     everything merged so far when they finish.
 //   * every block folds its top-2 into a per-query 64-bit slot with a CAS loop;
 //     the last block to arrive for a query block (agent-scope ticket) decodes
 //     the slots to (int32 idx, int32 dist) and restores the merge state, so a
 //     call is ONE kernel: no memset, no partial tables, no merge kernel.
-// Measured VALU issue costs on gfx950 (tools/ubench/valu_rate.hip): v_xor is in
-// the 2-cycle class per wave64, v_bcnt / v_min / v_med3 / v_cmp / shifts in the
-// 4-cycle class, so a pair costs >= 8*2 + 8*4 = 48 SIMD cycles nominally; their
-// SUSTAINED rates at 8 waves/SIMD are 2.54 and 4.48 cycles (class_order.hip),
-// i.e. 56.2 cycles per row, which is what this kernel runs at.  SGPR or DPP
-// operands make v_xor a 4-cycle op, which is why train rows come from LDS into
-// VGPRs.
+//   * several independent searches can share one launch (bf_top2_batch_kernel).
 #include "internal.h"
 #include "bf_scan_sgpr.h"
 #include <stdio.h>

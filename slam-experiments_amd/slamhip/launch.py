@@ -340,11 +340,12 @@ class Rendezvous:
         # external launcher such as torch.distributed.run - published by rank 0 in a file private to this user
         if token is None and os.environ.get("SLAM_RDZV_TOKEN"):
             token = bytes.fromhex(os.environ["SLAM_RDZV_TOKEN"])
+        from_file = False
         if token is None:
             if rank == 0:
                 token, self._token_file = _publish_token(name)
             else:
-                token = _read_token(name, timeout)
+                token, from_file = _read_token(name, timeout), True
         if len(token) != 32:
             raise RendezvousError("the rendezvous token must be 32 bytes")
         if rank == 0:
@@ -355,26 +356,31 @@ class Rendezvous:
             c = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
             try:
                 c.connect(_address(name))
-                self._conn = c
-                break
             except (ConnectionRefusedError, FileNotFoundError):
                 c.close()
                 if time.monotonic() > deadline:
                     raise RendezvousError(f"rank {rank}: no rendezvous server '{name}' after {timeout:.0f} s") from None
                 time.sleep(0.02)
-        if _peer_uid(self._conn) != os.getuid():
-            self._conn.close()
-            self._conn = None
-            raise RendezvousError(f"rank {rank}: the rendezvous server '{name}' belongs to another user")
-        self._conn.sendall(_HELLO.pack(_MAGIC, world, rank, token))
-        try:
-            self._conn.settimeout(timeout)
-            if _recv_exact(self._conn, 4) != _MAGIC:
-                raise EOFError("bad acknowledgement")
-        except (EOFError, OSError) as exc:
-            self._conn.close()
-            self._conn = None
-            raise RendezvousError(f"rank {rank}: the rendezvous server turned this rank away ({exc})") from None
+                continue
+            if _peer_uid(c) != os.getuid():
+                c.close()
+                raise RendezvousError(f"rank {rank}: the rendezvous server '{name}' belongs to another user")
+            try:
+                c.sendall(_HELLO.pack(_MAGIC, world, rank, token))
+                c.settimeout(max(0.05, deadline - time.monotonic()))
+                if _recv_exact(c, 4) != _MAGIC:
+                    raise EOFError("bad acknowledgement")
+                self._conn = c
+                return
+            except (EOFError, OSError) as exc:
+                c.close()
+                # A token read from the file may be a leftover of an earlier run that crashed under the same name (rank 0
+                # replaces the file when it starts, possibly after this rank looked): read it again and retry until the
+                # deadline.  A token that was handed down (environment, argument) is final.
+                if not from_file or time.monotonic() > deadline:
+                    raise RendezvousError(f"rank {rank}: the rendezvous server turned this rank away ({exc})") from None
+                time.sleep(0.05)
+                token = _read_token(name, max(0.05, deadline - time.monotonic()))
 
     def allgather(self, obj) -> list:
         """[obj of rank 0, obj of rank 1, ...] on every rank.  Every rank must make the same sequence of calls."""

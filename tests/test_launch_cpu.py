@@ -174,3 +174,38 @@ def test_external_launcher_token_file_is_private_and_removed():
     finally:
         if env_had is not None:
             os.environ["SLAM_RDZV_TOKEN"] = env_had
+
+
+def test_a_stale_token_file_of_a_crashed_run_does_not_lock_a_rank_out():
+    """Under an external launcher a rank may read the token file before rank 0 has replaced the leftover of an earlier,
+    crashed run of the same name: it is turned away once, reads the file again and joins."""
+    import threading
+    from slamhip import launch
+
+    name = f"test-stale-{os.getpid()}-{time.monotonic_ns()}"
+    env_had = os.environ.pop("SLAM_RDZV_TOKEN", None)
+    path = launch._token_path(name)
+    fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o600)
+    os.write(fd, b"\x5a" * 32)                              # the leftover
+    os.close(fd)
+    res = {}
+
+    def rank(r, delay):
+        time.sleep(delay)
+        rz = launch.Rendezvous(r, 2, name, timeout=20)
+        res[r] = rz.allgather(r)
+        rz.close()
+
+    try:
+        ts = [threading.Thread(target=rank, args=(1, 0.0)), threading.Thread(target=rank, args=(0, 0.5))]   # rank 1 looks first
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(40)
+        assert res == {0: [0, 1], 1: [0, 1]}
+        assert not os.path.exists(path)
+    finally:
+        if env_had is not None:
+            os.environ["SLAM_RDZV_TOKEN"] = env_had
+        if os.path.exists(path):
+            os.unlink(path)
