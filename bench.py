@@ -248,6 +248,63 @@ def pipelined_leg(query, train, steps: int) -> dict:
             "note": "searches alternate between two contexts (streams) of the same GPU; wall time / steps"}
 
 
+def bench_line(*, world, steps, warmup, loop_closure, n_query, n_train, n_local, wall_ms, dev_ms, rank_kernel_ms, launches,
+               collective, fallback_reason, rccl_version, plan, ok, train_replication) -> dict:
+    """The JSON line of a run from its measurements (pure: the CPU suite checks its schema and invariants without a GPU)."""
+    ms_per_step = wall_ms / steps
+    pairs = float(n_query) * float(n_train)
+    value = pairs / (ms_per_step * 1e-3)
+    kernel_ms = max(rank_kernel_ms)                             # the slowest rank's shard kernel bounds the step
+    local_pairs = float(n_local) * n_train                      # pairs one launch of the dominant kernel covers
+    alg_bytes = 32.0 * (n_local + n_train) + 16.0 * n_local     # each descriptor read once, top-2 written once
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+    lane_ops = local_pairs * OPS_PER_PAIR / (kernel_ms * 1e-3)
+    floor_ms = local_pairs / 64 * DUAL_ISSUE_CYCLES_PER_ROW / (256 * 4) / 2.4e9 * 1e3
+    if world == 1 and not loop_closure:
+        traffic, traffic_source = profiled_traffic("bf_top2_kernel")
+    else:
+        traffic, traffic_source = None, "PMC passes are collected on the default command only (N=1, 64k x 64k)"
+    if loop_closure:
+        metric = "descriptor pairs/sec BF-Hamming knn=2 loop-closure 512x2k all-to-all"
+        workload = (f"loop closure: {LC_KEYFRAMES} keyframes x {LC_ROWS} synthetic random 256-bit descriptors (rng seed 228) matched "
+                    f"all-to-all = 2^20 x 2^20 pairs per step, BF-Hamming knn=2 over the collection, result as "
+                    f"(imgIdx, trainIdx, distance) (BASELINE configs[3])")
+        sharding = (f"query keyframes / {world} ({LC_KEYFRAMES // world if LC_KEYFRAMES % world == 0 else 'about ' + str(LC_KEYFRAMES // world)} per rank), "
+                    f"train collection replicated ({train_replication}), all-gather of top-2, decode on every rank") if world > 1 else "single GPU"
+    else:
+        metric = "descriptor pairs/sec BF-Hamming knn=2 @64kx64k"
+        workload = ("65536x65536 synthetic random 256-bit descriptors (rng seeds 228/229), "
+                    "BF-Hamming knn=2 (BASELINE configs[2])")
+        sharding = f"query rows / {world}, train replicated, all-gather of top-2" if world > 1 else "single GPU"
+    return {
+        "metric": metric,
+        "value": value, "unit": "pairs/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "u32", "data": "synthetic",
+        "config": {"workload": workload, "n_query": n_query, "n_train": n_train, "sharding": sharding,
+                   "collective": collective, "collective_fallback_reason": fallback_reason,
+                   "rccl_version": rccl_version, "launch_plan": plan},
+        "device_ms_per_step": dev_ms / steps,
+        "parity_spot_check": ok,
+        "roofline": {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic, "traffic_source": traffic_source,
+            "kernel": "bf_top2_kernel", "kernel_ms": kernel_ms, "launches": launches,
+            "kernel_ms_per_rank": {"min": min(rank_kernel_ms), "max": max(rank_kernel_ms)},
+            "algorithmic_bytes_per_launch": alg_bytes,
+            "note": "contractual HBM figure on algorithmic bytes; the kernel is VALU-integer bound "
+                    "(1.2e-3 B/pair), see valu_int",
+            "valu_int": {"lane_ops_per_pair": OPS_PER_PAIR, "achieved_lane_ops_per_s": lane_ops,
+                         "peak_lane_ops_per_s": VALU_LANES_PER_S, "frac_of_32lane_peak": lane_ops / VALU_LANES_PER_S,
+                         "issue_floor_ms": floor_ms, "frac_of_issue_floor": floor_ms / kernel_ms,
+                         "issue_model": "16 wave64 VALU instructions per wave-row, 4 cycles each, two issue slots per SIMD "
+                                        "(one v_bcnt + one other at a time; measured in shader cycles, tools/ubench/cycles.hip), "
+                                        "at the NOMINAL 2.4 GHz: wall-clock fractions, at most 1 by construction; the in-kernel "
+                                        "clock and the cycles per wave-row at that clock are in profiles/ (tools/cycle_probe.py)"}},
+    }
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -398,59 +455,11 @@ def main() -> int:
 
     out = None
     if rank == 0:
-        ms_per_step = wall_ms / args.steps
-        pairs = float(n_query) * float(n_train)
-        value = pairs / (ms_per_step * 1e-3)
-        kernel_ms = max(rank_kernel_ms)                             # the slowest rank's shard kernel bounds the step
-        local_pairs = float(sm.n_local) * n_train                  # pairs one launch of the dominant kernel covers
-        alg_bytes = 32.0 * (sm.n_local + n_train) + 16.0 * sm.n_local   # each descriptor read once, top-2 written once
-        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-        lane_ops = local_pairs * OPS_PER_PAIR / (kernel_ms * 1e-3)
-        floor_ms = local_pairs / 64 * DUAL_ISSUE_CYCLES_PER_ROW / (256 * 4) / 2.4e9 * 1e3
-        if world == 1 and not loop_closure:
-            traffic, traffic_source = profiled_traffic("bf_top2_kernel")
-        else:
-            traffic, traffic_source = None, "PMC passes are collected on the default command only (N=1, 64k x 64k)"
-        if loop_closure:
-            metric = "descriptor pairs/sec BF-Hamming knn=2 loop-closure 512x2k all-to-all"
-            workload = (f"loop closure: {LC_KEYFRAMES} keyframes x {LC_ROWS} synthetic random 256-bit descriptors (rng seed 228) matched "
-                        f"all-to-all = 2^20 x 2^20 pairs per step, BF-Hamming knn=2 over the collection, result as "
-                        f"(imgIdx, trainIdx, distance) (BASELINE configs[3])")
-            sharding = (f"query keyframes / {world} ({LC_KEYFRAMES // world if LC_KEYFRAMES % world == 0 else 'about ' + str(LC_KEYFRAMES // world)} per rank), "
-                        f"train collection replicated ({sm.train_replication}), all-gather of top-2, decode on every rank") if world > 1 else "single GPU"
-        else:
-            metric = "descriptor pairs/sec BF-Hamming knn=2 @64kx64k"
-            workload = ("65536x65536 synthetic random 256-bit descriptors (rng seeds 228/229), "
-                        "BF-Hamming knn=2 (BASELINE configs[2])")
-            sharding = f"query rows / {world}, train replicated, all-gather of top-2" if world > 1 else "single GPU"
-        out = {
-            "metric": metric,
-            "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "u32", "data": "synthetic",
-            "config": {"workload": workload, "n_query": n_query, "n_train": n_train, "sharding": sharding,
-                       "collective": collective, "collective_fallback_reason": fallback_reason,
-                       "rccl_version": None if rccl_version is None else rccl_version.value,
-                       "launch_plan": ctx.plan_info(max(sm.n_local, 1), n_train)},
-            "device_ms_per_step": dev_ms / args.steps,
-            "parity_spot_check": ok,
-            "roofline": {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic, "traffic_source": traffic_source,
-                "kernel": "bf_top2_kernel", "kernel_ms": kernel_ms, "launches": launches,
-                "kernel_ms_per_rank": {"min": min(rank_kernel_ms), "max": max(rank_kernel_ms)},
-                "algorithmic_bytes_per_launch": alg_bytes,
-                "note": "contractual HBM figure on algorithmic bytes; the kernel is VALU-integer bound "
-                        "(1.2e-3 B/pair), see valu_int",
-                "valu_int": {"lane_ops_per_pair": OPS_PER_PAIR, "achieved_lane_ops_per_s": lane_ops,
-                             "peak_lane_ops_per_s": VALU_LANES_PER_S, "frac_of_32lane_peak": lane_ops / VALU_LANES_PER_S,
-                             "issue_floor_ms": floor_ms, "frac_of_issue_floor": floor_ms / kernel_ms,
-                             "issue_model": "16 wave64 VALU instructions per wave-row, 4 cycles each, two issue slots per SIMD "
-                                            "(one v_bcnt + one other at a time; measured in shader cycles, tools/ubench/cycles.hip), "
-                                            "at the NOMINAL 2.4 GHz: wall-clock fractions, at most 1 by construction; the in-kernel "
-                                            "clock and the cycles per wave-row at that clock are in profiles/ (tools/cycle_probe.py)"}},
-        }
+        out = bench_line(world=world, steps=args.steps, warmup=args.warmup, loop_closure=loop_closure, n_query=n_query, n_train=n_train,
+                         n_local=sm.n_local, wall_ms=wall_ms, dev_ms=dev_ms, rank_kernel_ms=rank_kernel_ms, launches=launches,
+                         collective=collective, fallback_reason=fallback_reason,
+                         rccl_version=None if rccl_version is None else rccl_version.value,
+                         plan=ctx.plan_info(max(sm.n_local, 1), n_train), ok=ok, train_replication=sm.train_replication)
         if world > 1:
             out["cpu_baseline"] = None
             out["cpu_baseline_note"] = "the CPU leg is timed at N=1 only (same arrays; see the N=1 line)"

@@ -97,3 +97,26 @@ for it in range(iters // 4):
         print(f"{it + 1} host-call iterations ok ({time.time() - t_start:.0f} s, cache hits {cache.hits}/{cache.calls})", flush=True)
 cache.free()
 print(f"host-call fuzz ok: {iters // 4} iterations, cache hits {cache.hits}/{cache.calls}, {time.time() - t_start:.0f} s")
+
+# ---- several searches in one launch (slam_bf_knn2_batch_u256): ragged batches against the oracle --------------------------
+t_start = time.time()
+for it in range(iters // 20):
+    B = int(rng.integers(1, 9))
+    pairs = []
+    for _ in range(B):
+        n = int(rng.choice([0, rng.integers(1, 70), rng.integers(1, 3000)]))
+        m = int(rng.choice([0, rng.integers(1, 70), rng.integers(1, 9000)]))
+        low = rng.integers(0, 3) == 0
+        gen = (lambda k: rng.choice(np.array([0, 255, 15], np.uint8), (k, 32))) if low else (lambda k: rng.integers(0, 256, (k, 32), dtype=np.uint8))
+        pairs.append((gen(n), gen(m)))
+    got = slamhip.knn_match_arrays_batch(pairs, ctx=ctx)
+    for (q, t), (gi, gd) in zip(pairs, got):
+        if len(q) == 0:
+            continue
+        ei, ed = oracle.bf_knn_c(q, t, 2, threads=8)
+        if not (np.array_equal(gi, ei) and np.array_equal(gd, ed)):
+            print(f"BATCH MISMATCH at iteration {it}: shapes {[(len(a), len(b)) for a, b in pairs]}", flush=True)
+            sys.exit(1)
+    if it % 100 == 99:
+        print(f"{it + 1} batches ok ({time.time() - t_start:.0f} s)", flush=True)
+print(f"batch fuzz ok: {iters // 20} batches, {time.time() - t_start:.0f} s")
