@@ -145,12 +145,16 @@ SLAM_API int slam_bf_knn2_u256_host(slam_ctx* ctx, const uint8_t* h_query, int64
  *   [3] lead_chunk    rows per leader chunk, a multiple of 32 (shipped: about one leader block per CU)
  *   [4] tail          number of linearly shrinking chunks at the end of the grid (shipped: 16); -1 = none
  *   [5] feed          how train rows reach the lanes at R = 1: 1 = through SGPRs (scalar loads, no LDS), -1 = through an LDS
- *                     tile (shipped: SGPRs when a chunk has at least 512 rows, the LDS tile below that) */
-#define SLAM_BF_KNOBS 6
+ *                     tile (shipped: SGPRs when a chunk has at least 512 rows, the LDS tile below that)
+ *   [6] cold          rows a chunk folds in WITHOUT a filter when it starts before anybody has published a bound for its
+ *                     queries, a multiple of 16 (shipped: see make_plan in bf_hamming.hip); -1 = none
+ *   [7] chunk         rows per uniform chunk for train sets below 16384 rows, a multiple of 32 (shipped: about one block
+ *                     per CU, 32 to 512 rows) */
+#define SLAM_BF_KNOBS 8
 SLAM_API int slam_bf_set_tuning(slam_ctx* ctx, const int32_t* h_knobs, int count);
 /* The launch plan slam_bf_knn2_u256 would use for N x M on this context: h_plan int32 [10] =
  * {R, query blocks, uniform chunk rows, chunks, leader rows, leader chunks, shrinking tail chunks, CUs,
- *  feed (1 = train rows through SGPRs, 0 = through an LDS tile), 0}. */
+ *  feed (1 = train rows through SGPRs, 0 = through an LDS tile), unfiltered rows at a cold chunk start}. */
 SLAM_API int slam_bf_plan_info(slam_ctx* ctx, int64_t N, int64_t M, int32_t* h_plan);
 /* Restore the matcher's per-context merge state to its idle values.  Every search leaves it clean by itself;
  * call this after a search failed part-way (the library does so on a failed launch).  Stream-ordered. */

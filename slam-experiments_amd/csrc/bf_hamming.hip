@@ -52,11 +52,13 @@
 typedef uint32_t u32;
 
 #define SLAM_TILE_ROWS 256          // train rows per LDS tile (8 KiB)
+#define SLAM_COLD_ROWS 128          // rows folded in unfiltered at a cold chunk start (make_plan; slam_bf_set_tuning [6])
 #define SLAM_GROUP_PAIRS 16         // (train rows) x (queries per lane) covered by one filter test
 #define SLAM_KEY_IDX_BITS 23
 #define SLAM_KEY_IDX_MASK 0x7FFFFFu
 #define SLAM_KEY_NONE 0xFFFFFFFFu
 #define SLAM_ACC_BIAS 0x80000000u
+#define SLAM_BOUND_IDLE 0x7F7F7F7Fu  // bound[] between launches (one byte pattern: restored by memset as well)
 
 // D = popcount(x) + acc in ONE instruction.  Written as asm because hipcc
 // re-associates __builtin_popcount(x)+acc chains into bcnt(x,0)+v_add3 (20
@@ -174,6 +176,24 @@ __device__ __forceinline__ void filter_update(const u32 (&acc)[U][R], u32 first_
     }
 }
 
+// The unfiltered form for the first rows of a chunk that starts without any bound: every row is folded into (b1, b2),
+// no test, no ballot, no branch.  A wave takes the update path for a row when ANY of its 64 lanes improves, i.e. on about
+// min(1, 128 / s) of its rows once s rows stand behind the thresholds: until a few hundred rows are known the filter
+// rejects nothing and costs a compare and a branch per row (a lone wave scanning a cold 256-row chunk measured 216 cycles
+// per row, profiles/r03_cycles.log 4096 x 4096, against 64 for its sixteen instructions).  The accumulators of these rows
+// start at 0, so the key is (acc << 23) | index: three instructions per row and pair.
+template <int R, int U>
+__device__ __forceinline__ void insert_rows(const u32 (&acc)[U][R], u32 first_train_idx, u32 (&b1)[R], u32 (&b2)[R]) {
+#pragma unroll
+    for (int u = 0; u < U; u++)
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const u32 key = (acc[u][r] << SLAM_KEY_IDX_BITS) | (first_train_idx + u);
+            b2[r] = umed3(b1[r], b2[r], key);
+            b1[r] = min(b1[r], key);
+        }
+}
+
 // Exchange the 2nd-best distance of the lane's queries with the blocks scanning other train chunks.
 // bound[q] only ever holds the 2nd-best distance over some subset of the train rows, i.e. an upper
 // bound of the final 2nd-best distance g: rows with d > g can be dropped, rows with d == g must stay
@@ -181,9 +201,11 @@ __device__ __forceinline__ void filter_update(const u32 (&acc)[U][R], u32 first_
 // (Measured and dropped: issuing the load at one share point and consuming it at the next, so that a wave never
 // sits on the round trip, makes every applied bound one segment staler - 64k x 64k 1528 -> 1551 us,
 // 8192 x 65536 212 -> 222 us, 2000 x 2000 21 -> 33 us.)
+// gk[r] keeps the last bound seen (an upper bound of the final 2nd-best distance for good: bound[] only decreases
+// during a launch); the epilogue uses it to skip merges that cannot matter, without another round trip.
 template <int R>
 __device__ __forceinline__ void share_bound(u32* __restrict__ bound, int qbase, int N, const u32 (&b2)[R],
-                                            u32 (&init)[R]) {
+                                            u32 (&init)[R], u32 (&gk)[R]) {
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const int qi = qbase + r * 64;
@@ -191,6 +213,7 @@ __device__ __forceinline__ void share_bound(u32* __restrict__ bound, int qbase, 
             const u32 g = __hip_atomic_load(&bound[qi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const u32 own = b2[r] >> SLAM_KEY_IDX_BITS;
             if (own < g) atomicMin(&bound[qi], own);
+            gk[r] = g;
             init[r] = SLAM_ACC_BIAS - min(own, g + 1);
         }
     }
@@ -205,22 +228,6 @@ struct bf_state {
     u32* arrivals;              // [query blocks]  how many chunk blocks have merged their result
 };
 
-// fold this block's (b1, b2) into best[q]: lock-free CAS loop, keys of different chunks are distinct.
-// Returns the 2nd key of the merged slot as this thread saw it (an upper bound of the final one).
-__device__ __forceinline__ u32 merge_into_slot(unsigned long long* slot, unsigned long long old, u32 b1, u32 b2) {
-    if (b1 == SLAM_KEY_NONE) return (u32)old;
-    while (true) {
-        const u32 o1 = (u32)(old >> 32), o2 = (u32)old;
-        const u32 k1 = min(o1, b1);
-        const u32 k2 = min(max(o1, b1), min(o2, b2));
-        const unsigned long long merged = ((unsigned long long)k1 << 32) | k2;
-        if (merged == old) return k2;
-        const unsigned long long prev = atomicCAS(slot, old, merged);
-        if (prev == old) return k2;
-        old = prev;
-    }
-}
-
 // grid.x = query blocks of 256*R rows, grid.y = train chunks: block (x, y) scans rows [tbl[y], tbl[y+1]).  Every block
 // merges its top-2 into st.best; the last block to arrive for a query block decodes (idx + train_base, dist) and
 // restores the merge state.  Blocks with y < lead are the leaders: short chunks at the head of the dispatch order that,
@@ -234,7 +241,8 @@ template <int R, bool SFEED>
 __device__ __forceinline__ void bf_top2_block(const uint4* __restrict__ q, int N, const uint4* __restrict__ t,
                                               const int* __restrict__ tbl, int lead, bf_state st, int train_base,
                                               int2* __restrict__ out_idx, int2* __restrict__ out_dist,
-                                              uint4* __restrict__ keep, const int bx, const int by, const int S) {
+                                              uint4* __restrict__ keep, const int bx, const int by, const int S,
+                                              const int cold_arg, const int uni, const int M) {
     __shared__ uint4 tile[2][SLAM_TILE_ROWS * 2 + 4];
     __shared__ u32 s_last;
     u32* __restrict__ bound = st.bound;
@@ -242,6 +250,11 @@ __device__ __forceinline__ void bf_top2_block(const uint4* __restrict__ q, int N
     const int lane = tid & 63, wave = tid >> 6;
     const int qbase = bx * (256 * R) + wave * (64 * R) + lane;
     const bool leader = by < lead;
+    // cold < 0 (make_plan): every chunk fits into its unfiltered start of -cold rows and the whole grid is resident at
+    // once - no block could ever use a bound published by another, so none is read or written (one round trip less in
+    // front of the scan).
+    const bool nobound = cold_arg < 0;
+    const int cold = cold_arg < 0 ? -cold_arg : cold_arg;
 
     u32 qr[R][8];
 #pragma unroll
@@ -258,16 +271,32 @@ __device__ __forceinline__ void bf_top2_block(const uint4* __restrict__ q, int N
         qr[r][0] = a.x; qr[r][1] = a.y; qr[r][2] = a.z; qr[r][3] = a.w;
         qr[r][4] = b.x; qr[r][5] = b.y; qr[r][6] = b.z; qr[r][7] = b.w;
     }
-    u32 b1[R], b2[R], init[R];
+    u32 b1[R], b2[R], init[R], gk[R];
 #pragma unroll
     for (int r = 0; r < R; r++) {
         b1[r] = SLAM_KEY_NONE;
         b2[r] = SLAM_KEY_NONE;
         init[r] = SLAM_ACC_BIAS - (SLAM_KEY_NONE >> SLAM_KEY_IDX_BITS);  // "distance 511": everything enters
+        gk[r] = SLAM_BOUND_IDLE;
     }
+    // A chunk starts COLD when nobody has published a bound for any of the wave's queries yet (the first dispatch round,
+    // every block of a frame-sized search): its first `cold` rows are then folded in without a filter (insert_rows).
+    // Blocks of later rounds pick up a bound at their first exchange and go straight to the filtered scan.
+    auto nobody_published = [&]() -> bool {
+        bool any = false;
+#pragma unroll
+        for (int r = 0; r < R; r++) any = any || gk[r] != SLAM_BOUND_IDLE;
+        return __ballot(any) == 0ull;
+    };
+    auto tighten = [&]() {
+#pragma unroll
+        for (int r = 0; r < R; r++) init[r] = max(init[r], SLAM_ACC_BIAS - (b2[r] >> SLAM_KEY_IDX_BITS));
+    };
 
-    const int t0 = tbl[by];
-    const int t1 = tbl[by + 1];
+    // uni > 0: the plan is `uni` rows per chunk throughout (single-round launches: frame-sized searches and everything up
+    // to a few thousand rows a side) - no boundary table to read, and none to upload in front of the launch
+    const int t0 = uni ? by * uni : tbl[by];
+    const int t1 = uni ? min(M, t0 + uni) : tbl[by + 1];
 
     if constexpr (SFEED) {
         // Train rows reach the lanes through SGPRs (SLAM_SCAN_GROUPS_ASM, bf_scan_sgpr.h): no LDS tile, no barrier, every
@@ -289,10 +318,12 @@ __device__ __forceinline__ void bf_top2_block(const uint4* __restrict__ q, int N
         u32 warm = touch(t0);
         asm volatile("" ::"v"(warm));                  // the first stretch: wait for it, the scan starts right away
         int row = t0;
+        bool is_cold = cold >= 16;
         while (row < t1) {
-            share_bound<R>(bound, qbase, N, b2, init);
+            if (!nobound) share_bound<R>(bound, qbase, N, b2, init, gk);
             const int done = row - t0;
-            const int seg = done < 16 ? 16 : (done < SLAM_TILE_ROWS ? done : SLAM_TILE_ROWS);
+            is_cold = is_cold && done == 0 && (nobound || nobody_published());
+            const int seg = is_cold ? cold : (done < 16 ? 16 : (done < SLAM_TILE_ROWS ? done : SLAM_TILE_ROWS));
             const int end = min(row + seg, t1);
             warm = (done == 0 || done >= SLAM_TILE_ROWS) ? touch(row + SLAM_TILE_ROWS) : 0u;
             int ng = __builtin_amdgcn_readfirstlane((end - row) >> 4);
@@ -300,8 +331,14 @@ __device__ __forceinline__ void bf_top2_block(const uint4* __restrict__ q, int N
                 const uint4* tp = t + 2 * (size_t)row;
                 u32 idx = (u32)__builtin_amdgcn_readfirstlane(row);
                 row += ng << 4;
-                SLAM_SCAN_GROUPS_ASM(qr[0], tp, ng, idx, b1[0], b2[0], init[0]);
+                if (is_cold) {
+                    SLAM_SCAN_GROUPS_COLD_ASM(qr[0], tp, ng, idx, b1[0], b2[0]);
+                    tighten();
+                } else {
+                    SLAM_SCAN_GROUPS_ASM(qr[0], tp, ng, idx, b1[0], b2[0], init[0]);
+                }
             }
+            is_cold = false;
             for (; row < end; row++) {                 // fewer than 16 rows left: only at the end of the train set
                 const uint4 x0 = t[2 * (size_t)row], y0 = t[2 * (size_t)row + 1];
                 u32 acc1[1][R];
@@ -331,7 +368,7 @@ __device__ __forceinline__ void bf_top2_block(const uint4* __restrict__ q, int N
                     nxt[i] = g < 2 * t1 ? t[(size_t)g] : make_uint4(0, 0, 0, 0);
                 }
             }
-            share_bound<R>(bound, qbase, N, b2, init);
+            if (!nobound) share_bound<R>(bound, qbase, N, b2, init, gk);
             const int cnt = __builtin_amdgcn_readfirstlane(min(SLAM_TILE_ROWS, t1 - tb));
             const uint4* tp = tile[buf];
             // software pipeline: the next row is read from LDS while the current one is computed (the last
@@ -341,35 +378,53 @@ __device__ __forceinline__ void bf_top2_block(const uint4* __restrict__ q, int N
             uint4 a0 = tp[0], c0 = tp[1];
             constexpr int U = SLAM_GROUP_PAIRS / R;   // 16 rows at R = 1 (59 VGPRs, still 8 waves/SIMD)
             static_assert(U >= 2 && U % 2 == 0, "row pipeline handles rows in pairs");
-            // A block starts with no threshold of its own, so in its first tile nearly every group takes the
-            // update path; there the bound is re-read after 16, 32, 64 and 128 rows (what the sibling blocks
-            // have scanned meanwhile tightens it), later once per tile.
+            // one group of U rows: rows are read through ONE running LDS address in a VGPR plus immediate offsets (the tile is
+            // padded by two rows so the read-ahead needs no wrap); the empty asm after every row block ties that address to the
+            // row's result, so the reads stay where they are written - rolling, one row ahead - instead of being
+            // batched by the scheduler (batched: 67 VGPRs, 7 waves/SIMD).  Against per-read scalar address arithmetic
+            // + v_mov from SGPR this saves ~1.5 VALU and ~8 SALU instructions per row: no change where the VALU is
+            // saturated (64k x 64k), 3-12 % on latency-bound sizes (4096 x 4096 30.5 -> 26.8 us).
+            auto group = [&](const u32 (&ini)[R], u32 (&acc)[U][R]) {
+                u32 base = lds_addr(tp + 2 * j);
+#pragma unroll
+                for (int u = 0; u < U; u += 2) {
+                    const uint4 a1 = lds_read16(base, (2 * u + 2) * 16), c1 = lds_read16(base, (2 * u + 3) * 16);
+                    row_acc<R>(qr, a0, c0, ini, acc[u]);
+                    asm volatile("" : "+v"(base) : "v"(acc[u][0]));
+                    a0 = lds_read16(base, (2 * u + 4) * 16);
+                    c0 = lds_read16(base, (2 * u + 5) * 16);
+                    row_acc<R>(qr, a1, c1, ini, acc[u + 1]);
+                    asm volatile("" : "+v"(base) : "v"(acc[u + 1][0]));
+                }
+            };
+            // A block starts with no threshold of its own.  When no sibling has published one either, its first `cold` rows
+            // are folded in unfiltered (insert_rows); after that - or from the start, when a bound was there - nearly every
+            // group still takes the update path for a while, and the bound is re-read after 16, 32, 64 and 128 rows (what
+            // the sibling blocks have scanned meanwhile tightens it), later once per tile.
             int seg_end = tb == t0 ? 16 : cnt;
+            if (tb == t0 && cold >= U && (nobound || nobody_published())) {
+                const int lim = min(cold, cnt);
+                u32 zero[R];
+#pragma unroll
+                for (int r = 0; r < R; r++) zero[r] = 0u;
+                for (; j + U <= lim; j += U) {
+                    u32 acc[U][R];
+                    group(zero, acc);
+                    insert_rows<R, U>(acc, (u32)(tb + j), b1, b2);
+                }
+                tighten();
+                if (j < cnt && !nobound) share_bound<R>(bound, qbase, N, b2, init, gk);
+                while (seg_end <= j) seg_end *= 2;
+            }
             while (true) {
                 const int lim = min(seg_end, cnt);
                 for (; j + U <= lim; j += U) {
                     u32 acc[U][R];
-                    // rows are read through ONE running LDS address in a VGPR plus immediate offsets (the tile is padded by two
-                    // rows so the read-ahead needs no wrap); the empty asm after every row block ties that address to the
-                    // row's result, so the reads stay where they are written - rolling, one row ahead - instead of being
-                    // batched by the scheduler (batched: 67 VGPRs, 7 waves/SIMD).  Against per-read scalar address arithmetic
-                    // + v_mov from SGPR this saves ~1.5 VALU and ~8 SALU instructions per row: no change where the VALU is
-                    // saturated (64k x 64k), 3-12 % on latency-bound sizes (4096 x 4096 30.5 -> 26.8 us).
-                    u32 base = lds_addr(tp + 2 * j);
-    #pragma unroll
-                    for (int u = 0; u < U; u += 2) {
-                        const uint4 a1 = lds_read16(base, (2 * u + 2) * 16), c1 = lds_read16(base, (2 * u + 3) * 16);
-                        row_acc<R>(qr, a0, c0, init, acc[u]);
-                        asm volatile("" : "+v"(base) : "v"(acc[u][0]));
-                        a0 = lds_read16(base, (2 * u + 4) * 16);
-                        c0 = lds_read16(base, (2 * u + 5) * 16);
-                        row_acc<R>(qr, a1, c1, init, acc[u + 1]);
-                        asm volatile("" : "+v"(base) : "v"(acc[u + 1][0]));
-                    }
+                    group(init, acc);
                     filter_update<R, U>(acc, (u32)(tb + j), b1, b2, init);
                 }
                 if (lim >= cnt) break;
-                share_bound<R>(bound, qbase, N, b2, init);
+                if (!nobound) share_bound<R>(bound, qbase, N, b2, init, gk);
                 seg_end *= 2;
             }
             for (; j < cnt; j++) {
@@ -389,19 +444,30 @@ __device__ __forceinline__ void bf_top2_block(const uint4* __restrict__ q, int N
 
     // ---- epilogue: merge, then the last arriver of this query block decodes ----------------------
     __builtin_amdgcn_s_setprio(0);   // the scan raised it (row_acc); merges and tickets run at the default priority
+    // Merge into best[q] = (1st key << 32 | 2nd key) with TWO 32-bit atomic minima instead of a 64-bit CAS loop: the 1st
+    // key goes into the high half with a returning atomicMin; whichever of (what was there, mine) lost, or my 2nd key if
+    // that is smaller, goes into the low half.  Every key is distinct, so: the high half ends as the smallest key m; m is
+    // never pushed into the low half (its holder pushes min(loser, own 2nd), both > m; everybody else pushes keys > m);
+    // and the second smallest key s always is (if s is somebody's 1st key it either loses against m directly or is
+    // displaced by m later, and the displacing thread pushes it; if it is the 2nd key of m's holder, that thread pushes
+    // it).  One round trip, no retries when the 16-64 chunk blocks of a query finish together - the CAS loop paid a
+    // load plus one round trip per lost race (epilogue of a 4096 x 4096 block: 6.6 us mean, profiles/r02_block_timeline.log).
+    // gk >= the final 2nd-best distance (share_bound): a block whose best row is farther than that cannot contribute and
+    // skips the atomics without looking (rows AT that distance may still win the tie on index).
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const int qi = qbase + r * 64;
-        if (qi < N) {
-            // bound[q] >= the final 2nd-best distance: a block whose best row is already farther than that
-            // cannot contribute, so most chunk blocks skip the CAS (one 4-byte load instead)
-            // (the slot is read alongside the bound: one round trip instead of two when the merge does happen)
-            const u32 g = __hip_atomic_load(&st.bound[qi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned long long slot = __hip_atomic_load(&st.best[qi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((b1[r] >> SLAM_KEY_IDX_BITS) <= g) {
-                const u32 k2 = merge_into_slot(&st.best[qi], slot, b1[r], b2[r]);
-                // leaders leave the exact 2nd-best distance of everything merged so far as the bound
-                if (leader && (k2 >> SLAM_KEY_IDX_BITS) < g) atomicMin(&st.bound[qi], k2 >> SLAM_KEY_IDX_BITS);
+        if (qi < N && b1[r] != SLAM_KEY_NONE && (b1[r] >> SLAM_KEY_IDX_BITS) <= gk[r]) {
+            u32* half = (u32*)&st.best[qi];                       // little endian: [0] = 2nd key, [1] = 1st key
+            const u32 o1 = atomicMin(half + 1, b1[r]);
+            const u32 push = min(max(o1, b1[r]), b2[r]);
+            if (leader) {
+                // leaders leave the 2nd key of everything merged so far as the bound (an upper bound of the final one:
+                // the low half only ever holds keys other than the smallest)
+                const u32 k2 = min(atomicMin(half, push), push);
+                if ((k2 >> SLAM_KEY_IDX_BITS) < gk[r]) atomicMin(&st.bound[qi], k2 >> SLAM_KEY_IDX_BITS);
+            } else if (push != SLAM_KEY_NONE) {
+                atomicMin(half, push);
             }
         }
     }
@@ -437,7 +503,7 @@ __device__ __forceinline__ void bf_top2_block(const uint4* __restrict__ q, int N
             out_dist[qi] = od;
             // restore the between-launch invariant for these queries (all other blocks are done with them)
             __hip_atomic_store(&st.best[qi], ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&st.bound[qi], 0x7F7F7F7Fu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&st.bound[qi], SLAM_BOUND_IDLE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     if (tid == 0) __hip_atomic_store(&st.arrivals[bx], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -448,9 +514,9 @@ __global__ __launch_bounds__(256) void bf_top2_kernel(const uint4* __restrict__ 
                                                       const uint4* __restrict__ t, const int* __restrict__ tbl,
                                                       int lead, bf_state st, int train_base,
                                                       int2* __restrict__ out_idx, int2* __restrict__ out_dist,
-                                                      uint4* __restrict__ keep) {
+                                                      uint4* __restrict__ keep, int cold, int uni, int M) {
     bf_top2_block<R, SFEED>(q, N, t, tbl, lead, st, train_base, out_idx, out_dist, keep, (int)blockIdx.x, (int)blockIdx.y,
-                            (int)gridDim.y);
+                            (int)gridDim.y, cold, uni, M);
 }
 
 // ---- several independent searches in ONE launch -------------------------------------------------------------------
@@ -462,7 +528,7 @@ __global__ __launch_bounds__(256) void bf_top2_kernel(const uint4* __restrict__ 
 struct bf_search {
     const uint4* q; const uint4* t; const int* tbl; int2* out_idx; int2* out_dist; uint4* keep;
     bf_state st;
-    int N, lead, S, qblocks, train_base, first_block;
+    int N, lead, S, qblocks, train_base, first_block, cold, uni, M, pad;
 };
 struct bf_batch {
     int count, pad;
@@ -476,7 +542,7 @@ __global__ __launch_bounds__(256) void bf_top2_batch_kernel(const bf_batch b) {
     const bf_search& p = b.s[i];
     const int local = id - p.first_block;           // x fastest, as in the single search: consecutive blocks = consecutive query blocks
     bf_top2_block<1, false>(p.q, p.N, p.t, p.tbl, p.lead, p.st, p.train_base, p.out_idx, p.out_dist, p.keep, local % p.qblocks,
-                            local / p.qblocks, p.S);
+                            local / p.qblocks, p.S, p.cold, p.uni, p.M);
 }
 
 // merge G decoded tables by (dist, idx)
@@ -524,13 +590,15 @@ struct bf_plan {
     int lead_rows;   // rows they cover together
     int tail;        // shrinking chunks at the end of the table
     int sfeed;       // 1: train rows through SGPRs (bf_scan_sgpr.h), 0: through an LDS tile
+    int cold;        // rows a chunk that starts without any bound folds in unfiltered (a multiple of 16; 0 = none)
+    int uni;         // > 0: every chunk has this many rows (no leaders, no tail) and the kernel needs no boundary table
 };
 
 // Tuning overrides live in the context (0 = heuristic): set through slam_bf_set_tuning, read under ctx->mu.
 extern "C" int slam_bf_set_tuning(slam_ctx* ctx, const int32_t* h_knobs, int count) {
     SLAM_REQUIRE(ctx, "slam_bf_set_tuning: null ctx");
     SLAM_REQUIRE(count >= 0 && count <= SLAM_BF_KNOBS && (h_knobs || count == 0), "bad knob array");
-    int k[SLAM_BF_KNOBS] = {0, 0, 0, 0, 0, 0};
+    int k[SLAM_BF_KNOBS] = {};
     for (int i = 0; i < count; i++) k[i] = h_knobs[i];
     SLAM_REQUIRE(k[0] == 0 || k[0] == 1 || k[0] == 2 || k[0] == 4 || k[0] == 8, "R must be 0, 1, 2, 4 or 8");
     SLAM_REQUIRE(k[1] >= 0 && k[1] <= 64, "blocks_per_cu out of range");
@@ -539,6 +607,8 @@ extern "C" int slam_bf_set_tuning(slam_ctx* ctx, const int32_t* h_knobs, int cou
     SLAM_REQUIRE(k[4] >= -1 && k[4] <= 4096, "tail out of range");
     SLAM_REQUIRE(k[5] >= -1 && k[5] <= 1, "feed must be 0 (heuristic), 1 (SGPRs) or -1 (LDS tile)");
     SLAM_REQUIRE(!(k[5] == 1 && k[0] > 1), "the SGPR-fed scan holds one query per lane (R = 1)");
+    SLAM_REQUIRE(k[6] >= -1 && k[6] <= (1 << 20) && (k[6] < 0 || k[6] % 16 == 0), "cold must be -1 or a multiple of 16 rows");
+    SLAM_REQUIRE(k[7] >= 0 && k[7] <= (1 << 22) && k[7] % 32 == 0, "chunk must be a multiple of 32 rows");
     std::lock_guard<std::mutex> g(ctx->mu);
     for (int i = 0; i < SLAM_BF_KNOBS; i++) ctx->bf_knob[i] = k[i];
     return SLAM_OK;
@@ -565,18 +635,25 @@ static void plan_uniform(const slam_ctx* ctx, int64_t N, int64_t M, int R, int b
     int64_t chunk = (M + S - 1) / S;
     chunk = (chunk + SLAM_TILE_ROWS - 1) / SLAM_TILE_ROWS * SLAM_TILE_ROWS;
     if (!forced && M < 16384) {
-        // Train sets below the leader regime.  Every block starts cold (nearly every group of its first rows takes the
-        // update path), so a chunk costs its rows PLUS a fixed start-up, and a small launch costs launch + drain latency
-        // on a grid that may not fill the chip.  Measured over single searches from 200 x 200 to 12000 x 12000 and over
-        // batches of 2-32 searches (tools/batch_sweep.py, profiles/r03_batch_chunk_sweep.log): the best chunk gives
-        // every CU about ONE block - as few cold starts as the chip can be filled with - but is never longer than 512
-        // rows (beyond that the grid drains badly) nor shorter than 32.  Frame-sized searches (the reference matches
-        // <= 200 x 200, slam.py:23) come out at 32-64 rows per block (200 x 200 21.6 -> 9.1 us when this was
-        // introduced), 4096 x 4096 at 256, everything from 6000 x 6000 and every well-filled batch at 512:
-        // 12000 x 12000 74 -> 62 us, 65536 x 4096 122 -> 101 us, sixteen 4096 x 4096 in one launch 186 -> 126 us.
-        int64_t c2 = (M * qb_all + ctx->num_cu - 1) / ctx->num_cu;
+        // Train sets below the leader regime: a small launch costs launch + drain latency on a grid that may not fill the
+        // chip.  Since round 3 a chunk that starts before anybody has published a bound folds its first rows in unfiltered
+        // (insert_rows: no compare, no branch per row), so a cold start is cheap and what counts is parallelism - a lone
+        // wave on a SIMD cannot pair its v_xor with another wave's v_bcnt and exposes every LDS read.  Measured over
+        // single searches from 200 x 200 to 12000 x 12000 and 65536 x 4096 (tools/ab_time.py with the chunk knob,
+        // profiles/r03_small_chunk_sweep.log): with c1 = the chunk that gives every CU ONE block, the best chunk is c1 up
+        // to 128 rows (frame-sized searches, the reference matches <= 200 x 200, slam.py:23: 32-64 rows per block) and
+        // about 8 sqrt(c1) beyond - 4096 x 4096: 128 rows (2 blocks per CU, 23.0 -> 17.6 us), 8192 x 8192: 256 (4 per CU,
+        // 40.2 -> 33.0 us), 12000 x 12000: 384, 65536 x 4096 and sixteen 4096 x 4096 in one launch: 512 (8 per CU).
+        int64_t c1 = (M * qb_all + ctx->num_cu - 1) / ctx->num_cu;
+        int64_t c2 = c1;
+        if (c1 > 128) {
+            int64_t r = 1;
+            while ((r + 1) * (r + 1) <= c1) r++;
+            c2 = 8 * r < 128 ? 128 : 8 * r;
+        }
         c2 = (c2 + 31) / 32 * 32;
         chunk = c2 < 32 ? 32 : (c2 > 512 ? 512 : c2);
+        if (ctx->bf_knob[7]) chunk = ctx->bf_knob[7];
     }
     p->chunk = (int)chunk;
 }
@@ -626,6 +703,13 @@ static bf_plan make_plan(slam_ctx* ctx, int64_t N, int64_t M, std::vector<int>* 
         if (tail > last_round) tail = last_round;
         if (tail > n_uniform / 2) tail = n_uniform / 2;
     }
+    // a grid that is resident all at once has no drain to shape: uniform chunks, which also need no boundary table
+    // (measured, profiles/r03_small_chunk_sweep.log: up to two blocks per CU the shrinking tail gains nothing - 200 x 200
+    // to 3000 x 3000 are 0.4-2.4 us faster without it and a search whose shape changes from frame to frame uploads no
+    // table; fuller one-round grids are dispatched over a longer time and keep it: 12000 x 12000 61 -> 57 us)
+    const int64_t qb_launch = qb_all > p.qblocks ? qb_all : p.qblocks;
+    const bool one_round = lead_rows == 0 && qb_launch * n_uniform <= slots;
+    if (one_round && qb_launch * n_uniform <= 2 * (int64_t)ctx->num_cu && k[4] == 0) tail = 0;
     std::vector<int>& b = *tbl;
     b.clear();
     b.push_back(0);
@@ -663,6 +747,10 @@ static bf_plan make_plan(slam_ctx* ctx, int64_t N, int64_t M, std::vector<int>* 
     // 145 -> 158 us, 65536 x 4096 122 -> 129 us.  Frame-sized calls read their rows from pinned host memory, where every
     // scalar load would be a PCIe round trip: they have chunks of at most one tile and stay on the LDS form as well.
     p.sfeed = p.R == 1 && (k[5] == 1 || (k[5] == 0 && p.chunk >= 2 * SLAM_TILE_ROWS)) ? 1 : 0;
+    p.cold = k[6] < 0 ? 0 : (k[6] ? k[6] : SLAM_COLD_ROWS);
+    p.uni = p.tail == 0 && p.lead == 0 ? p.chunk : 0;
+    // one round and no chunk longer than the unfiltered start: the kernel exchanges no bounds at all (passed as -cold)
+    if (one_round && p.chunk <= p.cold && p.lead == 0) p.cold = -p.cold;
     return p;
 }
 
@@ -673,7 +761,7 @@ extern "C" int slam_bf_plan_info(slam_ctx* ctx, int64_t N, int64_t M, int32_t* h
     const bf_plan p = make_plan(ctx, N, M, &tbl);
     h_plan[0] = p.R; h_plan[1] = p.qblocks; h_plan[2] = p.chunk; h_plan[3] = p.S;
     h_plan[4] = p.lead_rows; h_plan[5] = p.lead; h_plan[6] = p.tail; h_plan[7] = ctx->num_cu;
-    h_plan[8] = p.sfeed; h_plan[9] = 0;
+    h_plan[8] = p.sfeed; h_plan[9] = p.cold < 0 ? -p.cold : p.cold;
     return SLAM_OK;
 }
 
@@ -804,7 +892,8 @@ static int bf_pass(slam_ctx* ctx, const void* d_query, int64_t N, const void* d_
     bf_state st;
     if (int rc = bf_state_get(ctx, N, &st)) return rc;
     const int* d_tbl = nullptr;
-    if (int rc = bf_table_get(ctx, tbl, &d_tbl)) return rc;
+    if (!p.uni)
+        if (int rc = bf_table_get(ctx, tbl, &d_tbl)) return rc;
     const dim3 grid(p.qblocks, p.S), block(256);
     const uint4* q = (const uint4*)d_query;
     const uint4* t = (const uint4*)d_train;
@@ -814,7 +903,7 @@ static int bf_pass(slam_ctx* ctx, const void* d_query, int64_t N, const void* d_
     SLAM_HIP(hipGetLastError());
     if (int rc = slam_prof_begin(ctx)) return rc;
 #define SLAM_BF_LAUNCH(R_, F_) \
-    bf_top2_kernel<R_, F_><<<grid, block, 0, ctx->stream>>>(q, (int)N, t, d_tbl, p.lead, st, tb, oi, od, (uint4*)d_keep)
+    bf_top2_kernel<R_, F_><<<grid, block, 0, ctx->stream>>>(q, (int)N, t, d_tbl, p.lead, st, tb, oi, od, (uint4*)d_keep, p.cold, p.uni, (int)M)
     switch (p.R) {
         case 8: SLAM_BF_LAUNCH(8, false); break;
         case 4: SLAM_BF_LAUNCH(4, false); break;
@@ -925,16 +1014,17 @@ int slam_bf_knn2_batch_keep(slam_ctx* ctx, int64_t B, const slam_bf_search* h_se
         d.keep = h_keep ? (uint4*)h_keep[i] : nullptr;
         d.st.best = st.best + row0; d.st.bound = st.bound + row0; d.st.arrivals = st.arrivals + row0 / 256;
         d.N = (int)h.N; d.lead = p.lead; d.S = p.S; d.qblocks = p.qblocks; d.train_base = (int)h.train_base;
-        d.first_block = blocks;
+        d.first_block = blocks; d.cold = p.cold; d.uni = p.uni; d.M = (int)h.M;
         tbl_at.push_back(tables.size());
-        tables.insert(tables.end(), tbl.begin(), tbl.end());
+        if (!p.uni) tables.insert(tables.end(), tbl.begin(), tbl.end());
         blocks += p.qblocks * p.S;
         row0 += (h.N + 255) / 256 * 256;
     }
     if (batch.count == 0) return SLAM_OK;
     const int* d_tbl = nullptr;
-    if (int rc = bf_table_get(ctx, tables, &d_tbl)) return rc;
-    for (int i = 0; i < batch.count; i++) batch.s[i].tbl = d_tbl + tbl_at[i];
+    if (!tables.empty())
+        if (int rc = bf_table_get(ctx, tables, &d_tbl)) return rc;
+    for (int i = 0; i < batch.count; i++) batch.s[i].tbl = batch.s[i].uni ? nullptr : d_tbl + tbl_at[i];
     SLAM_HIP(hipGetLastError());
     if (int rc = slam_prof_begin(ctx)) return rc;
     bf_top2_batch_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(batch);

@@ -22,7 +22,7 @@ struct slam_ctx {
     int num_cu = 0;
     void* bf_state_mem = nullptr;                   // matcher merge state (best/bound/arrivals), clean between launches
     int64_t bf_state_rows = 0;
-    int bf_knob[SLAM_BF_KNOBS] = {0, 0, 0, 0, 0, 0};   // matcher tuning overrides (slam_bf_set_tuning), 0 = heuristic
+    int bf_knob[SLAM_BF_KNOBS] = {};                 // matcher tuning overrides (slam_bf_set_tuning), 0 = heuristic
     // chunk boundary tables of the recent searches: a ring of small slots + one big slot, device and pinned host
     void* bf_tbl_dev = nullptr;
     void* bf_tbl_host = nullptr;

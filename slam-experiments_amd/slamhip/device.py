@@ -79,16 +79,16 @@ class Context:
         return self.malloc(host.nbytes).upload(host)
 
     def set_tuning(self, R: int = 0, blocks_per_cu: int = 0, lead_rows: int = 0, lead_chunk: int = 0,
-                   tail: int = 0, feed: int = 0) -> None:
+                   tail: int = 0, feed: int = 0, cold: int = 0, chunk: int = 0) -> None:
         """Experiment knobs of the top-2 search on this context (``slam_bf_set_tuning``); no arguments = shipped plan."""
-        knobs = (ctypes.c_int32 * 6)(R, blocks_per_cu, lead_rows, lead_chunk, tail, feed)
-        check(self.lib.slam_bf_set_tuning(self.handle, knobs, 6))
+        knobs = (ctypes.c_int32 * 8)(R, blocks_per_cu, lead_rows, lead_chunk, tail, feed, cold, chunk)
+        check(self.lib.slam_bf_set_tuning(self.handle, knobs, 8))
 
     def plan_info(self, n: int, m: int) -> dict:
         """The launch plan the top-2 search would use for n x m (``slam_bf_plan_info``)."""
         p = (ctypes.c_int32 * 10)()
         check(self.lib.slam_bf_plan_info(self.handle, n, m, p))
-        return dict(zip(("R", "qblocks", "chunk", "chunks", "lead_rows", "lead_chunks", "tail_chunks", "cus", "sgpr_feed"), p))
+        return dict(zip(("R", "qblocks", "chunk", "chunks", "lead_rows", "lead_chunks", "tail_chunks", "cus", "sgpr_feed", "cold_rows"), p))
 
     def sync(self) -> None:
         check(self.lib.slam_sync(self.handle))

@@ -1,5 +1,6 @@
 """GPU: the launch plan of the top-2 search (leader chunks that publish exact bounds, shrinking chunks at the end of
-the grid, queries per lane, train rows through an LDS tile or through SGPRs) must not change a single bit of the result."""
+the grid, queries per lane, train rows through an LDS tile or through SGPRs, the unfiltered start of a cold chunk, the
+chunk length of small train sets) must not change a single bit of the result."""
 import numpy as np
 import pytest
 
@@ -36,9 +37,44 @@ def test_every_plan_shape_is_bit_identical(gpu_ctx, n, m):
             for lead_rows, lead_chunk in ((-1, 0), (256, 0), (512, 64), (1024, 32), (0, 0)):
                 for bpc, tail in ((0, 0), (8, 5), (0, 64), (32, -1)):
                     for feed in ((-1, 1) if R == 1 else (0,)):     # R = 1: both ways of feeding the train rows
-                        ctx.set_tuning(R=R, blocks_per_cu=bpc, lead_rows=lead_rows, lead_chunk=lead_chunk, tail=tail, feed=feed)
+                        for cold in (0, -1, 16, 1024):             # shipped / no unfiltered start / one group / whole chunks
+                            ctx.set_tuning(R=R, blocks_per_cu=bpc, lead_rows=lead_rows, lead_chunk=lead_chunk, tail=tail, feed=feed,
+                                           cold=cold)
+                            idx, dist = _search(ctx, dq, n, dt, m, tab)
+                            assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist), (R, lead_rows, lead_chunk, bpc, tail, feed, cold)
+    finally:
+        ctx.set_tuning()
+        for o in (tab, dq, dt):
+            o.free()
+
+
+@pytest.mark.parametrize("n,m", [(200, 200), (300, 1500), (4100, 4000), (70, 16383)])
+def test_small_train_sets_any_chunk_length_and_cold_start(gpu_ctx, n, m):
+    """Train sets below the leader regime: forced chunk lengths (one-round grids run without a boundary table and
+    without any bound exchange when the chunk fits into the unfiltered start) against the oracle, ties included."""
+    import slamhip
+    from oracle import oracle
+
+    ctx = gpu_ctx
+    rng = np.random.default_rng(n + 3 * m)
+    q = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    t = rng.integers(0, 256, (m, 32), dtype=np.uint8)
+    t[m - 1] = t[0]                      # the same row in the first and in the last chunk
+    t[m // 2 + 1] = t[m // 2]            # and next to each other
+    q[0] = t[0]
+    q[1] = t[m // 2]
+    ridx, rdist = oracle.bf_knn_c(q, t, 2, threads=8)
+    assert ridx[0].tolist() == [0, m - 1] and ridx[1].tolist() == [m // 2, m // 2 + 1]
+    dq, dt = slamhip.DeviceDescriptors(ctx, q), slamhip.DeviceDescriptors(ctx, t)
+    tab = slamhip.Top2Table(ctx, n)
+    try:
+        for chunk in (0, 32, 96, 128, 160, 512, 4096):
+            for cold in (0, -1, 16, 64, 4096):
+                for tail in (0, -1, 3):
+                    for feed in (-1, 1):
+                        ctx.set_tuning(chunk=chunk, cold=cold, tail=tail, feed=feed)
                         idx, dist = _search(ctx, dq, n, dt, m, tab)
-                        assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist), (R, lead_rows, lead_chunk, bpc, tail, feed)
+                        assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist), (chunk, cold, tail, feed)
     finally:
         ctx.set_tuning()
         for o in (tab, dq, dt):
@@ -65,6 +101,13 @@ def test_plan_tables_and_degenerate_inputs(gpu_ctx):
     assert ctx.plan_info(65536, 65536)["sgpr_feed"] == 1 and ctx.plan_info(1 << 20, 1 << 20)["sgpr_feed"] == 1
     assert ctx.plan_info(65536, 4096)["sgpr_feed"] == 1 and ctx.plan_info(8192, 65536)["sgpr_feed"] == 1
     assert ctx.plan_info(4096, 4096)["sgpr_feed"] == 0 and ctx.plan_info(200, 200)["sgpr_feed"] == 0
+    # small train sets: one block per CU up to 128 rows a chunk, about 8 sqrt(that) beyond; no tail up to two blocks per CU
+    cus = ctx.plan_info(200, 200)["cus"]
+    if cus == 256:
+        for (n_, m_), chunk in (((200, 200), 32), ((2000, 2000), 64), ((4096, 4096), 128), ((8192, 8192), 256), ((65536, 4096), 512)):
+            p = ctx.plan_info(n_, m_)
+            assert p["chunk"] == chunk and p["cold_rows"] == 128 and p["lead_rows"] == 0, (n_, m_, p)
+        assert ctx.plan_info(4096, 4096)["tail_chunks"] == 0 and ctx.plan_info(12000, 12000)["tail_chunks"] > 0
     n, m = 700, 20000
     rng = np.random.default_rng(3)
     q = rng.integers(0, 256, (n, 32), dtype=np.uint8)

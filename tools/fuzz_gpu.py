@@ -42,7 +42,8 @@ for it in range(iters):
             t[rng.integers(0, m, len(rows) // 2 + 1)] = t[rows[: len(rows) // 2 + 1]]
     knobs = dict(R=int(rng.choice([0, 1, 1, 2, 4, 8])), blocks_per_cu=int(rng.choice([0, 0, 1, 4, 16, 64])),
                  lead_rows=int(rng.choice([0, 0, -1, 32, 256, 1024, 4096])), lead_chunk=int(rng.choice([0, 0, 32, 64, 512])),
-                 tail=int(rng.choice([0, 0, -1, 1, 5, 64])))
+                 tail=int(rng.choice([0, 0, -1, 1, 5, 64])), cold=int(rng.choice([0, 0, -1, 16, 48, 128, 1024])),
+                 chunk=int(rng.choice([0, 0, 0, 32, 96, 256, 1024])))
     knobs["feed"] = int(rng.choice([0, -1, 1])) if knobs["R"] in (0, 1) else 0     # train rows through the LDS tile / SGPRs
     ctx.set_tuning(**knobs)
     dq, dt = slamhip.DeviceDescriptors(ctx, q), slamhip.DeviceDescriptors(ctx, t)

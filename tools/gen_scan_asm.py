@@ -35,16 +35,34 @@ def row(r, sbase):
 
 
 nsub = 16 // G
-body = [line(f"s_mov_b64 s[{SP}:{SP + 1}], %[tp]")] + load_set(SA, 0) + [line("Lgroup_%=:")]
-for k in range(nsub):
-    cur, nxt = (SA, SB) if k % 2 == 0 else (SB, SA)
-    body.append(line("s_waitcnt lgkmcnt(0)"))
+
+
+def prologue():
+    return [line(f"s_mov_b64 s[{SP}:{SP + 1}], %[tp]")] + load_set(SA, 0) + [line("Lgroup_%=:")]
+
+
+def loads_for(k):
+    nxt = SB if k % 2 == 0 else SA
+    out = [line("s_waitcnt lgkmcnt(0)")]
     if k < nsub - 1:
-        body += load_set(nxt, G * (k + 1))
+        out += load_set(nxt, G * (k + 1))
     else:   # the next group's first rows, unless this is the last group of the call: nothing is read past the requested rows
-        body += [line("s_cmp_eq_u32 %[ng], 1"), line("s_cbranch_scc1 Lnopf_%=")] + load_set(nxt, 16) + [line("Lnopf_%=:")]
+        out += [line("s_cmp_eq_u32 %[ng], 1"), line("s_cbranch_scc1 Lnopf_%=")] + load_set(nxt, 16) + [line("Lnopf_%=:")]
+    return out
+
+
+def epilogue():
+    return [line(f"s_add_u32 s{SP}, s{SP}, 0x200"), line(f"s_addc_u32 s{SP + 1}, s{SP + 1}, 0"),
+            line("s_add_u32 %[idx], %[idx], 16"), line("s_sub_u32 %[ng], %[ng], 1"), line("s_cmp_lg_u32 %[ng], 0"),
+            '"s_cbranch_scc1 Lgroup_%="']
+
+
+# ---- the filtered scan -------------------------------------------------------------------------------------------------
+body = prologue()
+for k in range(nsub):
+    body += loads_for(k)
     for i in range(G):
-        body += row(G * k + i, cur + 8 * i)
+        body += row(G * k + i, (SA if k % 2 == 0 else SB) + 8 * i)
 # filter: a row improved some lane <=> its accumulator is below 2^31 there <=> the unsigned minimum of the sixteen is.
 # Eight v_min3_u32 / v_min_u32 instead of a tree of fifteen v_and_b32: min3 can only use the v_bcnt issue slot, but the
 # scan is bound by the OTHER slot (eight v_xor + the filter against eight v_bcnt), so halving the filter's instructions
@@ -58,10 +76,37 @@ for u in range(16):   # update path: a row whose ballot is empty is skipped (wav
              line(f"v_lshl_or_b32 v{VKEY}, v{VKEY}, 23, s{STMP}"), line(f"v_med3_u32 %[b2], %[b1], %[b2], v{VKEY}"),
              line(f"v_min_u32 %[b1], %[b1], v{VKEY}"), line(f"Lskip{u}_%=:")]
 body += [line(f"v_lshrrev_b32 v{VKEY}, 23, %[b2]"), line(f"v_sub_u32 v{VKEY}, 0x80000000, v{VKEY}"),
-         line(f"v_max_u32 %[init], %[init], v{VKEY}"), line("Lnofire_%=:"),
-         line(f"s_add_u32 s{SP}, s{SP}, 0x200"), line(f"s_addc_u32 s{SP + 1}, s{SP + 1}, 0"),
-         line("s_add_u32 %[idx], %[idx], 16"), line("s_sub_u32 %[ng], %[ng], 1"), line("s_cmp_lg_u32 %[ng], 0"),
-         '"s_cbranch_scc1 Lgroup_%="']
+         line(f"v_max_u32 %[init], %[init], v{VKEY}"), line("Lnofire_%=:")] + epilogue()
+
+
+# ---- the unfiltered scan (the first rows of a chunk that starts without a threshold) -----------------------------------
+# Every row is folded into (b1, b2): no group test, no ballots, no branches.  A row's accumulator starts at 0, so the key
+# is (acc << 23) | index.  The fold of row r is issued behind the v_xor half of row r + 1 (its inputs are long complete),
+# in the raised-priority half, where the other one-slot instructions (v_bcnt) are.
+def insert(r):
+    return [line(f"s_add_u32 s{STMP}, %[idx], {r}"), line(f"v_lshlrev_b32 v{VKEY}, 23, v{ACC + r}"),
+            line(f"v_or_b32 v{VKEY}, s{STMP}, v{VKEY}"), line(f"v_med3_u32 %[b2], %[b1], %[b2], v{VKEY}"),
+            line(f"v_min_u32 %[b1], %[b1], v{VKEY}")]
+
+
+def cold_row(r, sbase):
+    out = [line("s_setprio 0")]
+    out += [line(f"v_xor_b32 v{TMP + w}, s{sbase + w}, %[q{w}]") for w in range(8)]
+    out += [line("s_setprio 2")]
+    if r:
+        out += insert(r - 1)
+    out += [line(f"v_bcnt_u32_b32 v{ACC + r}, v{TMP}, 0")]
+    out += [line(f"v_bcnt_u32_b32 v{ACC + r}, v{TMP + w}, v{ACC + r}") for w in range(1, 8)]
+    return out
+
+
+cold = prologue()
+for k in range(nsub):
+    cold += loads_for(k)
+    for i in range(G):
+        cold += cold_row(G * k + i, (SA if k % 2 == 0 else SB) + 8 * i)
+cold += insert(15) + epilogue()
+
 clob = ", ".join([f'"v{i}"' for i in range(ACC, VKEY + 1)] + [f'"s{i}"' for i in range(STMP, SA + 16 * G)] + ['"vcc"', '"scc"', '"memory"'])
 ins = ", ".join(f'[q{w}] "v"(Q_[{w}])' for w in range(8)) + ', [tp] "s"(TP_)'
 text = f'''// bf_scan_sgpr.h - GENERATED by tools/gen_scan_asm.py; edit the generator, not this file.
@@ -94,6 +139,15 @@ text = f'''// bf_scan_sgpr.h - GENERATED by tools/gen_scan_asm.py; edit the gene
 #define SLAM_SCAN_GROUPS_ASM(Q_, TP_, NG_, IDX_, B1_, B2_, INIT_) \\
     asm volatile( \\
 ''' + "".join(f"        {l} \\\n" for l in body) + f'''        : [b1] "+v"(B1_), [b2] "+v"(B2_), [init] "+v"(INIT_), [ng] "+s"(NG_), [idx] "+s"(IDX_) \\
+        : {ins} \\
+        : {clob})
+// SLAM_SCAN_GROUPS_COLD_ASM(Q_, TP_, NG_, IDX_, B1_, B2_): the same scan WITHOUT a threshold - every row is folded into
+// (B1_, B2_).  For the first rows of a chunk that starts with no bound (nearly every row would take the update path: a wave
+// fires when any of its 64 lanes improves, i.e. on about 128 / s of its rows after s rows): four more instructions per
+// row instead of a compare and a branch per row.  Accumulators start at 0, the key is (acc << 23) | index.
+#define SLAM_SCAN_GROUPS_COLD_ASM(Q_, TP_, NG_, IDX_, B1_, B2_) \\
+    asm volatile( \\
+''' + "".join(f"        {l} \\\n" for l in cold) + f'''        : [b1] "+v"(B1_), [b2] "+v"(B2_), [ng] "+s"(NG_), [idx] "+s"(IDX_) \\
         : {ins} \\
         : {clob})
 '''
