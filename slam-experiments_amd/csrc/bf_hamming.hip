@@ -467,18 +467,26 @@ __device__ __forceinline__ void bf_top2_block(const uint4* __restrict__ q, int N
                 const u32 k2 = min(atomicMin(half, push), push);
                 if ((k2 >> SLAM_KEY_IDX_BITS) < gk[r]) atomicMin(&st.bound[qi], k2 >> SLAM_KEY_IDX_BITS);
             } else if (push != SLAM_KEY_NONE) {
-                atomicMin(half, push);
+                // returning form on purpose: "the value is back" means the minimum has been taken at the memory side, which is
+                // what the arrival ticket below relies on (a no-return atomic is only known to have been sent)
+                const u32 o2 = atomicMin(half, push);
+                asm volatile("" ::"v"(o2));
             }
         }
     }
-    // Arrival ticket (cdna_hip_programming.md G16, counter form): the merges above are returning
-    // agent-scope atomics, already complete when the CAS loop exits; drain, barrier, one release,
-    // one relaxed ticket.  Placement-independent: nothing relies on which XCD a block runs on.
+    // Arrival ticket.  Everything a block contributes travels in agent-scope atomics that RETURN (the two minima above):
+    // they are executed at the memory side (MI355X_MICROARCH.md, "Global float atomics": never in an XCD's L2, nothing stays
+    // dirty in L2), and a returned value means the operation is done there.  So: every wave waits for its returns, block
+    // barrier, one relaxed ticket; the block that draws the last ticket reads the slots back with agent-scope loads (L1 is
+    // bypassed; the acquire in front of them is kept as cheap insurance - it runs once per query block).  The G16 counter
+    // form has an agent-scope RELEASE fence (buffer_wbl2 sc1) in front of the ticket; it writes back dirty L2 lines, of
+    // which this hand-off has none, and cost 1.7 us on the critical path of every block: 4096 x 4096 18.4 -> 16.7 us,
+    // 2000 x 2000 10.7 -> 9.4 us, the 1/8 shard 159.9 -> 154.8 us without it (profiles/r03_ab_cold_start.log; the guide
+    // lists "agent atomics both sides" among the valid forms).  Placement-independent: nothing relies on which XCD a block
+    // runs on.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const u32 ticket = __hip_atomic_fetch_add(&st.arrivals[bx], 1u, __ATOMIC_RELAXED,
                                                   __HIP_MEMORY_SCOPE_AGENT);
         s_last = ticket == (u32)S - 1 ? 1u : 0u;

@@ -31,9 +31,9 @@ s = s.replace('typedef uint32_t u32;', 'typedef uint32_t u32;\n__device__ unsign
               '{ return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &p, sizeof(p)); }', 1)
 assert s.count('g_trace[') == 5, "trace hooks did not apply: the kernel source changed"
 open(sys.argv[2], 'w').write(s)
-old = '__hip_atomic_store(&st.bound[qi], 0x7F7F7F7Fu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);'
+old = '__hip_atomic_store(&st.bound[qi], SLAM_BOUND_IDLE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);'
 assert src.count(old) == 1, "keep-bound hook did not apply: the kernel source changed"
-open(sys.argv[3], 'w').write(src.replace(old, '__hip_atomic_store(&st.bound[qi], k2 == SLAM_KEY_NONE ? 0x7F7F7F7Fu : '
+open(sys.argv[3], 'w').write(src.replace(old, '__hip_atomic_store(&st.bound[qi], k2 == SLAM_KEY_NONE ? SLAM_BOUND_IDLE : '
                                               '(k2 >> SLAM_KEY_IDX_BITS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);'))
 g = '    if (__builtin_expect(__ballot((int)m >= 0) != 0ull, 0)) {\n'
 r = '            if (U > 1 && __ballot((int)mu >= 0) == 0ull) continue;\n'
