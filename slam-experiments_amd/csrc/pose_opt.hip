@@ -7,8 +7,8 @@
 // Python callback from g2o's C++ (frontend.py:272-291), <= 200 edges x <= 40
 // iterations x 2 callbacks.  Here one 256-thread workgroup keeps the problem
 // on chip: every evaluation is a block-wide pass over the observations
-// (residual, 2x6 Jacobian, Huber weight, 28 sums through LDS in a fixed order,
-// so results are run-to-run identical), lane 0 solves the damped 6x6 system by
+// (residual, 2x6 Jacobian, Huber weight, 28 sums by one DPP pairing + LDS in a fixed
+// order, so results are run-to-run identical), lane 0 solves the damped 6x6 system by
 // LDL^T and drives g2o's published LM schedule.
 //
 // Measured and dropped (round 3, tools/pose_lm_probe.py, profiles/r03_pose_lm.log): the whole refinement on ONE wave
@@ -34,6 +34,8 @@
 
 #define PO_THREADS 256
 #define PO_TERMS 28   // 21 (upper H) + 6 (b) + 1 (robust chi2 of the active edges)
+#define PO_RED_STRIDE (PO_THREADS / 2 + 8)   // doubles per term in the reduction buffer: padded, so the 16-value reads of
+                                             // thread (term, segment) fall on different LDS banks for different terms
 #define PO_STAGE 512  // observations kept in LDS (3 + 2 + 1 doubles and a flag each: 24.5 KiB)
 
 struct po_cam { double fx, fy, cx, cy; };
@@ -127,6 +129,66 @@ __device__ __forceinline__ bool po_solve(const double* s, const double* b, doubl
     return true;
 }
 
+// Residual and robust cost of one edge at pose T (frontend.py:272-277 and g2o's RobustKernelHuber).  Written with explicit
+// fma() for every multiply-add so that the compiler has no contraction left to decide: po_evaluate and po_costs call it in
+// different surroundings and must round identically - at convergence the gain ratio's numerator is a difference of two
+// sums that agree to the last bits, and a reduction or contraction that differed between the two passes would turn every
+// such trial into a coin toss (measured: 29 -> 33-37 "accepted" steps at 200 edges).
+struct po_edge { double X, Y, Z, e0, e1, c2, w, rho; };
+__device__ __forceinline__ po_edge po_edge_at(const double* T, double px, double py, double pz, double2 m, po_cam cam,
+                                              double delta) {
+    po_edge r;
+    r.X = fma(T[0], px, fma(T[1], py, fma(T[2], pz, T[3])));
+    r.Y = fma(T[4], px, fma(T[5], py, fma(T[6], pz, T[7])));
+    r.Z = fma(T[8], px, fma(T[9], py, fma(T[10], pz, T[11])));
+    r.e0 = m.x - fma(cam.fx, r.X, cam.cx * r.Z) / r.Z;      // frontend.py:275-277
+    r.e1 = m.y - fma(cam.fy, r.Y, cam.cy * r.Z) / r.Z;
+    r.c2 = fma(r.e0, r.e0, r.e1 * r.e1);
+    r.w = 1.0;                                               // Huber: rho' and rho
+    r.rho = r.c2;
+    if (delta > 0.0) {
+        const double en = sqrt(r.c2);
+        if (en > delta) { r.w = delta / en; r.rho = fma(2.0 * delta, en, -(delta * delta)); }
+    }
+    return r;
+}
+
+// sum over the block of `nterms` per-thread values each (acc[0..nterms)), run-to-run identical: adjacent lanes are paired
+// by a DPP swap, the even lane of each pair parks the pair's sum in LDS (128 values per term), thread (term, segment) adds
+// its 16 values in a rotated but fixed order (bank-conflict free through the padded term stride; the rotation depends on the segment only, so a term
+// rounds the same whatever its index), then one thread per term adds the 8 partials.  Three barriers; every thread returns
+// with the sums in out[0..nterms).
+__device__ __forceinline__ double po_swap_adjacent(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, 0xB1, 0xF, 0xF, true);          // quad_perm [1,0,3,2]
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0xB1, 0xF, 0xF, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+template <int NT>
+__device__ __forceinline__ void po_block_sums(double (&acc)[NT], double* red, double* part, double* out) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < NT; i++) acc[i] += po_swap_adjacent(acc[i]);
+    if (!(tid & 1)) {
+#pragma unroll
+        for (int i = 0; i < NT; i++) red[i * PO_RED_STRIDE + (tid >> 1)] = acc[i];
+    }
+    __syncthreads();
+    if (tid < NT * 8) {
+        const double* r = red + (tid >> 3) * PO_RED_STRIDE + (tid & 7) * 16;
+        double sum = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) sum += r[(k + (tid & 7)) & 15];
+        part[tid] = sum;
+    }
+    __syncthreads();
+    if (tid < NT) {
+        const double* q = part + tid * 8;
+        out[tid] = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
+    }
+    __syncthreads();
+}
+
 // One block-wide evaluation at pose T: sums[0..20] = upper H, [21..26] = b, [27] = robust chi2 over the
 // active edges; chi2[o] = e.e for every edge.  Every thread returns with the sums in `out` (shared).
 // points / meas / active / chi2 are generic pointers: the LDS copies when the problem is staged, else global.
@@ -136,26 +198,15 @@ __device__ __forceinline__ void po_evaluate(const double* T, const double* point
 #pragma unroll
     for (int i = 0; i < PO_TERMS; i++) acc[i] = 0.0;
     for (int o = threadIdx.x; o < O; o += PO_THREADS) {
-        const double px = points[o * 3], py = points[o * 3 + 1], pz = points[o * 3 + 2];
-        const double X = T[0] * px + T[1] * py + T[2] * pz + T[3];
-        const double Y = T[4] * px + T[5] * py + T[6] * pz + T[7];
-        const double Z = T[8] * px + T[9] * py + T[10] * pz + T[11];
-        const double2 m = meas[o];
-        const double e0 = m.x - (cam.fx * X + cam.cx * Z) / Z;      // frontend.py:275-277
-        const double e1 = m.y - (cam.fy * Y + cam.cy * Z) / Z;
-        const double c2 = e0 * e0 + e1 * e1;
-        chi2[o] = c2;
+        const po_edge g = po_edge_at(T, points[o * 3], points[o * 3 + 1], points[o * 3 + 2], meas[o], cam, delta);
+        chi2[o] = g.c2;
         if (!active[o]) continue;
+        const double X = g.X, Y = g.Y, Z = g.Z, e0 = g.e0, e1 = g.e1, w = g.w;
         const double Zinv = 1.0 / (Z + 1e-18), Zinv2 = Zinv * Zinv;  // frontend.py:284-291
         const double j0[6] = {cam.fx * X * Y * Zinv2, -cam.fx - cam.fx * X * X * Zinv2, cam.fx * Y * Zinv,
                               -cam.fx * Zinv, 0.0, cam.fx * X * Zinv2};
         const double j1[6] = {cam.fy + cam.fy * Y * Y * Zinv2, -cam.fy * X * Y * Zinv2, -cam.fy * X * Zinv, 0.0,
                               -cam.fy * Zinv, cam.fy * Y * Zinv2};
-        double w = 1.0, rho = c2;                                    // Huber: rho' and rho (g2o RobustKernelHuber)
-        if (delta > 0.0) {
-            const double en = sqrt(c2);
-            if (en > delta) { w = delta / en; rho = 2.0 * delta * en - delta * delta; }
-        }
         int t = 0;
 #pragma unroll
         for (int a = 0; a < 6; a++)
@@ -163,39 +214,41 @@ __device__ __forceinline__ void po_evaluate(const double* T, const double* point
             for (int b = a; b < 6; b++) acc[t++] += w * (j0[a] * j0[b] + j1[a] * j1[b]);
 #pragma unroll
         for (int a = 0; a < 6; a++) acc[21 + a] += w * (j0[a] * e0 + j1[a] * e1);
-        acc[27] += rho;
+        acc[27] += g.rho;
     }
-    // 28 sums over 256 threads through LDS, in two batches of 14 (28 KiB): thread (term, segment) adds its 32
-    // values in a rotated but fixed order (bank-conflict free, run-to-run identical), then 8 partials per term.
-    // Cross-lane shuffles cost ~170 dependent LDS round trips here; this is 2 x (14 writes + 32 reads) per thread.
-    const int tid = threadIdx.x;
+    po_block_sums<PO_TERMS>(acc, red, part, out);
+}
+
+// The robust cost of the active edges at up to PO_SPEC candidate poses in ONE block-wide pass (no Jacobians, no normal
+// equations): costs[j] for every j with solved[j].  Same per-edge arithmetic as po_evaluate; the sums travel through LDS
+// in the same rotated fixed order.
+#define PO_SPEC 9     // trials 1..9 of an iteration, evaluated together after trial 0 was turned down
+__device__ __forceinline__ void po_costs(const double* Tk /*[PO_SPEC][12]*/, const int* solved, const double* points,
+                                         const double2* meas, const uint8_t* active, int O, po_cam cam, double delta,
+                                         double* red, double* part, double* costs) {
+    double acc[PO_SPEC];
 #pragma unroll
-    for (int half = 0; half < 2; half++) {
-        __syncthreads();   // previous readers of red / part / out are done
+    for (int j = 0; j < PO_SPEC; j++) acc[j] = 0.0;
+    for (int o = threadIdx.x; o < O; o += PO_THREADS) {
+        if (!active[o]) continue;
+        const double px = points[o * 3], py = points[o * 3 + 1], pz = points[o * 3 + 2];
+        const double2 m = meas[o];
 #pragma unroll
-        for (int i = 0; i < PO_TERMS / 2; i++) red[i * PO_THREADS + tid] = acc[half * (PO_TERMS / 2) + i];
-        __syncthreads();
-        if (tid < (PO_TERMS / 2) * 8) {
-            const double* r = red + (tid >> 3) * PO_THREADS + (tid & 7) * 32;
-            double sum = 0.0;
-#pragma unroll
-            for (int k = 0; k < 32; k++) sum += r[(k + tid) & 31];
-            part[half * (PO_TERMS / 2) * 8 + tid] = sum;
+        for (int j = 0; j < PO_SPEC; j++) {
+            if (!solved[j]) continue;                                   // block-uniform
+            acc[j] += po_edge_at(Tk + 12 * j, px, py, pz, m, cam, delta).rho;
         }
     }
-    __syncthreads();
-    if (tid < PO_TERMS) {
-        const double* q = part + tid * 8;
-        out[tid] = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
-    }
-    __syncthreads();
+    po_block_sums<PO_SPEC>(acc, red, part, costs);
 }
 
 struct po_shared {
-    double red[(PO_TERMS / 2) * PO_THREADS];
+    double red[PO_TERMS * PO_RED_STRIDE];
     double part[PO_TERMS * 8];
     double cur[PO_TERMS], cand[PO_TERMS];
     double T0[12], T[12], Tn[12];
+    double Tk[PO_SPEC * 12], scale_k[PO_SPEC], cost_k[PO_SPEC];   // the speculated trials of one iteration
+    int solved_k[PO_SPEC];
     double lambda, ni;
     int flag, accepted, nactive;
 };
@@ -225,52 +278,85 @@ __device__ __forceinline__ int po_run(po_shared& sh, const double* points, const
         }
         __syncthreads();
         for (int it = 0; it < prm.iterations && nactive > 0; it++) {
-            bool ok = false;
-            for (int trial = 0; trial < 10; trial++) {  // maxTrialsAfterFailure
-                // lane 0 proposes a step
-                if (tid == 0) {
-                    double dx[6];
-                    sh.flag = po_solve(cur, cur + 21, sh.lambda, dx) ? 1 : 0;
-                    if (sh.flag) {
-                        po_apply_update(dx, T, Tn);
-                        double scale = 1e-3;
-                        for (int i = 0; i < 6; i++) scale += dx[i] * (sh.lambda * dx[i] - cur[21 + i]);
-                        cand[0] = scale;                // parked until the evaluation overwrites cand
-                    }
-                }
-                __syncthreads();
-                const int solved = sh.flag;
-                const double scale = cand[0];
-                __syncthreads();                        // everybody has read sh.flag / cand[0] before lane 0 moves on
-                if (!solved) {
-                    if (tid == 0) { sh.lambda *= sh.ni; sh.ni *= 2.0; }
-                    __syncthreads();
-                    continue;
-                }
-                po_evaluate(Tn, points, meas, active, O, cam, delta, chi2, red, part, cand);
-                if (tid == 0) {
-                    const double rho = (cur[27] - cand[27]) / scale;
-                    if (rho > 0.0 && isfinite(cand[27])) {
-                        for (int i = 0; i < 12; i++) T[i] = Tn[i];
-                        for (int i = 0; i < PO_TERMS; i++) cur[i] = cand[i];
-                        const double g = 2.0 * rho - 1.0;
-                        sh.lambda *= fmax(1.0 / 3.0, fmin(1.0 - g * g * g, 2.0 / 3.0));
-                        sh.ni = 2.0;
-                        sh.accepted++;
-                        sh.flag = 2;
-                    } else {
-                        sh.lambda *= sh.ni;
-                        sh.ni *= 2.0;
-                        sh.flag = isfinite(sh.lambda) ? 1 : 3;
-                    }
-                }
-                __syncthreads();
-                const int verdict = sh.flag;
-                __syncthreads();                        // read before the next trial's lane 0 overwrites it
-                if (verdict == 2) { ok = true; break; }
-                if (verdict == 3) break;
+            // ---- the ten trials of this iteration are PROPOSED together.  A trial that is turned down changes nothing but
+            // the damping (lambda *= ni, ni *= 2), so the candidates of all ten trials are known in advance: lane j of
+            // wave 0 solves with the damping trial j would meet and builds its pose - ten solves for the latency of one.
+            // Trial 0 is then evaluated in full (cost, H, b); only when it is turned down does ONE more pass give the costs
+            // of trials 1..9, and lane 0 walks them in order: the first one the sequential loop would have accepted is
+            // accepted, with the damping that loop would have had.  g2o's schedule ends every round on ten rejected trials
+            // (maxTrialsAfterFailure): ten sequential solve + evaluation pairs (38 us of a 67 us round at 200 edges)
+            // become one solve and two passes.
+            if (tid <= PO_SPEC) {
+                double lam = sh.lambda, ni = sh.ni;
+                for (int k = 0; k < tid; k++) { lam *= ni; ni *= 2.0; }
+                double dx[6];
+                const bool ok_j = po_solve(cur, cur + 21, lam, dx);
+                double sc = 1e-3;
+                for (int i = 0; i < 6; i++) sc += dx[i] * (lam * dx[i] - cur[21 + i]);
+                // one instruction stream for all ten lanes: only the destinations differ
+                double* pose_j = tid == 0 ? Tn : sh.Tk + 12 * (tid - 1);
+                double* scale_j = tid == 0 ? cand : sh.scale_k + (tid - 1);          // cand[0]: parked until the evaluation overwrites cand
+                int* solved_j = tid == 0 ? &sh.flag : sh.solved_k + (tid - 1);
+                *solved_j = ok_j ? 1 : 0;
+                if (ok_j) { po_apply_update(dx, T, pose_j); *scale_j = sc; }
             }
-            if (!ok) break;
+            __syncthreads();
+            const int solved = sh.flag;
+            const double scale = cand[0];
+            __syncthreads();                        // everybody has read sh.flag / cand[0] before lane 0 moves on
+            if (solved) po_evaluate(Tn, points, meas, active, O, cam, delta, chi2, red, part, cand);
+            if (tid == 0) {
+                const double rho = solved ? (cur[27] - cand[27]) / scale : -1.0;
+                if (solved && rho > 0.0 && isfinite(cand[27])) {
+                    for (int i = 0; i < 12; i++) T[i] = Tn[i];
+                    for (int i = 0; i < PO_TERMS; i++) cur[i] = cand[i];
+                    const double g = 2.0 * rho - 1.0;
+                    sh.lambda *= fmax(1.0 / 3.0, fmin(1.0 - g * g * g, 2.0 / 3.0));
+                    sh.ni = 2.0;
+                    sh.accepted++;
+                    sh.flag = 2;
+                } else {
+                    sh.lambda *= sh.ni;
+                    sh.ni *= 2.0;
+                    sh.flag = (!solved || isfinite(sh.lambda)) ? 1 : 3;   // an unsolvable system never ends the iteration
+                }
+            }
+            __syncthreads();
+            int verdict = sh.flag;
+            __syncthreads();                        // read before lane 0 overwrites it
+            if (verdict == 2) continue;
+            if (verdict == 3) break;
+            // ---- trial 0 was turned down: the costs of trials 1..9 in one pass
+            po_costs(sh.Tk, sh.solved_k, points, meas, active, O, cam, delta, red, part, sh.cost_k);
+            if (tid == 0) {
+                double lam = sh.lambda, ni = sh.ni;
+                int v = 1;
+                for (int j = 0; j < PO_SPEC; j++) {
+                    if (sh.solved_k[j]) {
+                        const double rho = (cur[27] - sh.cost_k[j]) / sh.scale_k[j];
+                        if (rho > 0.0 && isfinite(sh.cost_k[j])) {
+                            for (int i = 0; i < 12; i++) T[i] = sh.Tk[12 * j + i];
+                            const double g = 2.0 * rho - 1.0;
+                            lam *= fmax(1.0 / 3.0, fmin(1.0 - g * g * g, 2.0 / 3.0));
+                            ni = 2.0;
+                            sh.accepted++;
+                            v = 2;
+                            break;
+                        }
+                    }
+                    lam *= ni;
+                    ni *= 2.0;
+                    if (sh.solved_k[j] && !isfinite(lam)) { v = 3; break; }
+                }
+                sh.lambda = lam;
+                sh.ni = ni;
+                sh.flag = v;
+            }
+            __syncthreads();
+            verdict = sh.flag;
+            __syncthreads();
+            if (verdict != 2) break;                // ten trials turned down (or the damping overflowed): the round's iterations end
+            po_evaluate(T, points, meas, active, O, cam, delta, chi2, red, part, cur);   // H, b, cost at the accepted pose
         }
         // chi2 at the pose this round ended on, then the outlier / level decision (frontend.py:366-379)
         po_evaluate(T, points, meas, active, O, cam, delta, chi2, red, part, cand);
