@@ -37,6 +37,9 @@ import time
 from typing import List, Optional, Sequence, Tuple
 
 
+_SLOT = struct.Struct("<q")
+
+
 class RendezvousError(RuntimeError):
     pass
 
@@ -403,7 +406,84 @@ class Rendezvous:
     def barrier(self) -> None:
         self.allgather(None)
 
+    # ---- a barrier for timing brackets ---------------------------------------------------------------------------------
+    # barrier() is a round trip through rank 0's socket per rank, served one after the other: 0.17 ms with two ranks,
+    # 0.63 ms with eight (measured, 8 host cores).  Inside a timed bracket of twenty 0.16 ms steps that is 16 % of the
+    # measurement.  spin_barrier() keeps one 64-byte slot per rank in a shared-memory file: a rank writes its barrier
+    # count into its own slot and polls the others' - a few microseconds.  The file is created by rank 0 (0600, random
+    # name, O_EXCL), its path travels over the authenticated socket, every rank checks owner and mode before mapping, and
+    # rank 0 unlinks it once everybody has it mapped.  A rank that never arrives is a RendezvousError after `timeout`
+    # seconds, naming it; where /dev/shm cannot be used every rank falls back to barrier().
+    def _spin_setup(self) -> None:
+        import mmap
+        import secrets
+        import stat
+
+        path = None
+        if self.rank == 0:
+            try:
+                path = f"/dev/shm/slamhip-bar-{os.getpid()}-{secrets.token_hex(8)}"
+                fd = os.open(path, os.O_CREAT | os.O_EXCL | os.O_RDWR, 0o600)
+                os.ftruncate(fd, 64 * self.world)
+                os.close(fd)
+            except OSError:
+                path = None
+        path = self.bcast(path)
+        mm = None
+        if path is not None:
+            try:
+                fd = os.open(path, os.O_RDWR | getattr(os, "O_NOFOLLOW", 0))
+                try:
+                    st = os.fstat(fd)
+                    if st.st_uid != os.getuid() or not stat.S_ISREG(st.st_mode) or st.st_mode & 0o077 or st.st_size != 64 * self.world:
+                        raise OSError("not this run's barrier file")
+                    mm = mmap.mmap(fd, 64 * self.world)
+                finally:
+                    os.close(fd)
+            except (OSError, ValueError):
+                mm = None
+        ok = all(self.allgather(mm is not None))
+        if self.rank == 0 and path is not None:
+            try:
+                os.unlink(path)                     # the mappings stay valid
+            except OSError:
+                pass
+        if not ok and mm is not None:
+            mm.close()
+            mm = None
+        self._spin_mm, self._spin_gen = mm, 0
+        self._spin_ready = True
+
+    def spin_barrier(self) -> None:
+        """Low-latency barrier over shared memory (see above); every rank must call it in the same sequence."""
+        if self._conn is None:
+            return
+        if not getattr(self, "_spin_ready", False):
+            self._spin_setup()
+        mm = self._spin_mm
+        if mm is None:
+            return self.barrier()
+        self._spin_gen += 1
+        gen = self._spin_gen
+        _SLOT.pack_into(mm, 64 * self.rank, gen)
+        start = time.monotonic()
+        for r in range(self.world):
+            spins = 0
+            while _SLOT.unpack_from(mm, 64 * r)[0] < gen:
+                spins += 1
+                if spins & 0x3FF == 0:
+                    waited = time.monotonic() - start
+                    if waited > self.timeout:
+                        missing = [q for q in range(self.world) if _SLOT.unpack_from(mm, 64 * q)[0] < gen]
+                        raise RendezvousError(f"rank {self.rank}: ranks {missing} did not reach the barrier within {self.timeout:.0f} s")
+                    if waited > 0.002:
+                        time.sleep(0.0001)          # somebody is far behind: stop burning a core
+
     def close(self) -> None:
+        mm = getattr(self, "_spin_mm", None)
+        if mm is not None:
+            mm.close()
+            self._spin_mm = None
         if self._conn is not None:
             try:
                 _send(self._conn, ("bye", None))

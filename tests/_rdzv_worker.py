@@ -21,6 +21,30 @@ def main() -> int:
         assert ident == b"\x07" * 128
         assert rz.bcast("from-last" if rank == world - 1 else None, src=world - 1) == "from-last"
         rz.barrier()
+        if mode in ("spin", "spin-die"):
+            # the shared-memory barrier of timing brackets: nobody passes barrier k before everybody has written k
+            import time
+            order = []
+            for k in range(300):
+                if rank == k % world:
+                    time.sleep(0.0002)                 # a different straggler every time
+                if mode == "spin-die" and rank == 1 and k == 100:
+                    os._exit(3)
+                try:
+                    rz.spin_barrier()
+                except RendezvousError as exc:
+                    print(f"RDZV_ERROR rank {rank}: {exc}", flush=True)
+                    return 5
+                order.append(time.monotonic())
+            stamps = rz.allgather(order)
+            for k in range(299):                       # nobody leaves barrier k + 1 before everybody has entered it, i.e. left barrier k
+                assert max(s_[k] for s_ in stamps) <= min(s_[k + 1] for s_ in stamps) + 1e-4, k
+            t0 = time.perf_counter()
+            for _ in range(500):
+                rz.spin_barrier()
+            per_call = (time.perf_counter() - t0) / 500
+            if rank == 0:
+                print(f"SPIN_US {per_call * 1e6:.1f}", flush=True)
         if mode == "skip" and rank == 1:
             return 0                                   # leaves without the collective the others are about to enter
         if mode == "die" and rank == 1:

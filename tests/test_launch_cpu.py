@@ -32,6 +32,17 @@ def test_a_rank_that_leaves_or_dies_becomes_an_error_not_a_hang():
         assert "RDZV_ERROR rank 0" in out.stdout, (mode, out.stdout, out.stderr[-2000:])
 
 
+def test_spin_barrier_orders_ranks_and_a_dead_rank_is_an_error():
+    """The shared-memory barrier bench.py brackets its timed region with: correct under stragglers, cheap, bounded."""
+    out, _ = _run("spin", 4)
+    assert out.returncode == 0 and "RDZV_OK" in out.stdout, (out.stdout, out.stderr[-2000:])
+    us = float(out.stdout.split("SPIN_US")[1].split()[0])
+    assert us < 400.0, us                                # the socket barrier is 170-630 us; this one is a few (loaded CI boxes: be generous)
+    out, dt = _run("spin-die", 3, {"RDZV_TIMEOUT": "4"})
+    assert out.returncode != 0 and dt < 60, (out.returncode, dt)
+    assert "RDZV_ERROR rank 0" in out.stdout and "[1]" in out.stdout, (out.stdout, out.stderr[-2000:])
+
+
 def test_identity_from_both_launch_styles():
     from slamhip.launch import Rendezvous, from_env
 
@@ -46,6 +57,7 @@ def test_identity_from_both_launch_styles():
     rz = Rendezvous(0, 1, "unused")
     assert rz.allgather(5) == [5] and rz.bcast(7) == 7
     rz.barrier()
+    rz.spin_barrier()
     rz.close()
 
 
