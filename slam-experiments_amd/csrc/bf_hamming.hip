@@ -536,7 +536,7 @@ __global__ __launch_bounds__(256) void bf_top2_kernel(const uint4* __restrict__ 
 struct bf_search {
     const uint4* q; const uint4* t; const int* tbl; int2* out_idx; int2* out_dist; uint4* keep;
     bf_state st;
-    int N, lead, S, qblocks, train_base, first_block, cold, uni, M, pad;
+    int N, lead, S, qblocks, train_base, first_block, cold, uni, M, sfeed;
 };
 struct bf_batch {
     int count, pad;
@@ -549,8 +549,13 @@ __global__ __launch_bounds__(256) void bf_top2_batch_kernel(const bf_batch b) {
     while (i + 1 < b.count && id >= b.s[i + 1].first_block) i++;
     const bf_search& p = b.s[i];
     const int local = id - p.first_block;           // x fastest, as in the single search: consecutive blocks = consecutive query blocks
-    bf_top2_block<1, false>(p.q, p.N, p.t, p.tbl, p.lead, p.st, p.train_base, p.out_idx, p.out_dist, p.keep, local % p.qblocks,
-                            local / p.qblocks, p.S, p.cold, p.uni, p.M);
+    const int bx = local % p.qblocks, by = local / p.qblocks;
+    if (p.sfeed)   // block-uniform: the search's train rows travel through SGPRs (short or long chunks in device memory)
+        bf_top2_block<1, true>(p.q, p.N, p.t, p.tbl, p.lead, p.st, p.train_base, p.out_idx, p.out_dist, p.keep, bx, by, p.S, p.cold,
+                               p.uni, p.M);
+    else
+        bf_top2_block<1, false>(p.q, p.N, p.t, p.tbl, p.lead, p.st, p.train_base, p.out_idx, p.out_dist, p.keep, bx, by, p.S, p.cold,
+                                p.uni, p.M);
 }
 
 // merge G decoded tables by (dist, idx)
@@ -674,7 +679,15 @@ static void plan_uniform(const slam_ctx* ctx, int64_t N, int64_t M, int R, int b
 //   uniform:  chunks of p.chunk rows.
 //   tail:     the last `tail` chunks shrink linearly, so the blocks dispatched last (the youngest waves, which the
 //             age-ordered VALU arbiter serves last) have the least left to do when the grid drains.
-static bf_plan make_plan(slam_ctx* ctx, int64_t N, int64_t M, std::vector<int>* tbl, int64_t qb_all = 0) {
+// rows_on_host: the train rows lie in the context's pinned staging block (frame-sized host calls let the kernel read them
+// over PCIe): they must not travel through scalar loads.
+static bool bf_rows_on_host(const slam_ctx* ctx, const void* p) {
+    const char* c = (const char*)p;
+    return ctx->io_host && c >= (const char*)ctx->io_host && c < (const char*)ctx->io_host + ctx->io_host_bytes;
+}
+
+static bf_plan make_plan(slam_ctx* ctx, int64_t N, int64_t M, std::vector<int>* tbl, int64_t qb_all = 0,
+                         bool rows_on_host = false) {
     std::lock_guard<std::mutex> g(ctx->mu);
     const int* k = ctx->bf_knob;
     bf_plan p;
@@ -749,12 +762,16 @@ static bf_plan make_plan(slam_ctx* ctx, int64_t N, int64_t M, std::vector<int>* 
     p.tail = (int)ts.size();
     p.S = (int)b.size() - 1;
     // Which way the train rows travel.  Through SGPRs the scan needs no LDS read (the chip holds a higher clock) but every
-    // call of the scan exposes a scalar-load latency, and a chunk's first 256 rows make five calls: measured
-    // (profiles/r03_ab_sgpr_feed.log) it wins where a block scans many rows - 64k x 64k (chunks of 2048) 1217 -> 1080-1091 us,
-    // 2^20 x 2^20 304 -> 272 ms, 32768 x 65536 623 -> 599 us - and loses where chunks are one tile: 20000 x 20000 (256 rows)
-    // 145 -> 158 us, 65536 x 4096 122 -> 129 us.  Frame-sized calls read their rows from pinned host memory, where every
-    // scalar load would be a PCIe round trip: they have chunks of at most one tile and stay on the LDS form as well.
-    p.sfeed = p.R == 1 && (k[5] == 1 || (k[5] == 0 && p.chunk >= 2 * SLAM_TILE_ROWS)) ? 1 : 0;
+    // call of the scan exposes a scalar-load latency: measured (profiles/r03_ab_sgpr_feed.log) it wins where a block scans
+    // many rows - 64k x 64k (chunks of 2048) 1217 -> 1080-1091 us, 2^20 x 2^20 304 -> 272 ms, 32768 x 65536 623 -> 599 us -
+    // and lost where chunks were one tile and the filter still ran from the first row (20000 x 20000, 256 rows: 145 -> 158 us).
+    // With the unfiltered start a chunk of up to 128 rows is ONE call of the scan with no exchange in between, and there
+    // the SGPR form wins again (no tile staging, no barrier, two waves per SIMD do not expose LDS latency:
+    // profiles/r03_ab_cold_start.log feed=1, 4096 x 4096 18.4 -> 17.3 us, 2000 x 2000 10.7 -> 9.8 us; 8192 x 8192 with
+    // 256-row chunks 32.8 -> 35.6 us stays on the LDS form).  Rows that lie in pinned host memory (frame-sized host calls)
+    // always take the LDS form: every scalar load would be a PCIe round trip.
+    const bool short_chunks = p.chunk <= SLAM_COLD_ROWS && lead_rows == 0 && !rows_on_host;
+    p.sfeed = p.R == 1 && (k[5] == 1 || (k[5] == 0 && (p.chunk >= 2 * SLAM_TILE_ROWS || short_chunks))) ? 1 : 0;
     p.cold = k[6] < 0 ? 0 : (k[6] ? k[6] : SLAM_COLD_ROWS);
     p.uni = p.tail == 0 && p.lead == 0 ? p.chunk : 0;
     // one round and no chunk longer than the unfiltered start: the kernel exchanges no bounds at all (passed as -cold)
@@ -896,7 +913,7 @@ extern "C" int slam_bf_reset_state(slam_ctx* ctx) {
 static int bf_pass(slam_ctx* ctx, const void* d_query, int64_t N, const void* d_train, int64_t M,
                    int64_t train_base, int32_t* d_idx, int32_t* d_dist, void* d_keep) {
     std::vector<int> tbl;
-    const bf_plan p = make_plan(ctx, N, M, &tbl);
+    const bf_plan p = make_plan(ctx, N, M, &tbl, 0, bf_rows_on_host(ctx, d_train));
     bf_state st;
     if (int rc = bf_state_get(ctx, N, &st)) return rc;
     const int* d_tbl = nullptr;
@@ -1014,7 +1031,7 @@ int slam_bf_knn2_batch_keep(slam_ctx* ctx, int64_t B, const slam_bf_search* h_se
             continue;
         }
         std::vector<int> tbl;
-        const bf_plan p = make_plan(ctx, h.N, h.M, &tbl, qb_all);
+        const bf_plan p = make_plan(ctx, h.N, h.M, &tbl, qb_all, bf_rows_on_host(ctx, h.d_train));
         SLAM_REQUIRE(p.R == 1, "slam_bf_knn2_batch_u256 runs at one query per lane: clear the R override (slam_bf_set_tuning)");
         bf_search& d = batch.s[batch.count++];
         d.q = (const uint4*)h.d_query; d.t = (const uint4*)h.d_train;
@@ -1022,7 +1039,7 @@ int slam_bf_knn2_batch_keep(slam_ctx* ctx, int64_t B, const slam_bf_search* h_se
         d.keep = h_keep ? (uint4*)h_keep[i] : nullptr;
         d.st.best = st.best + row0; d.st.bound = st.bound + row0; d.st.arrivals = st.arrivals + row0 / 256;
         d.N = (int)h.N; d.lead = p.lead; d.S = p.S; d.qblocks = p.qblocks; d.train_base = (int)h.train_base;
-        d.first_block = blocks; d.cold = p.cold; d.uni = p.uni; d.M = (int)h.M;
+        d.first_block = blocks; d.cold = p.cold; d.uni = p.uni; d.M = (int)h.M; d.sfeed = p.sfeed;
         tbl_at.push_back(tables.size());
         if (!p.uni) tables.insert(tables.end(), tbl.begin(), tbl.end());
         blocks += p.qblocks * p.S;

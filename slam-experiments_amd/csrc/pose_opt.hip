@@ -308,8 +308,7 @@ __device__ __forceinline__ int po_run(po_shared& sh, const double* points, const
             if (tid == 0) {
                 const double rho = solved ? (cur[27] - cand[27]) / scale : -1.0;
                 if (solved && rho > 0.0 && isfinite(cand[27])) {
-                    for (int i = 0; i < 12; i++) T[i] = Tn[i];
-                    for (int i = 0; i < PO_TERMS; i++) cur[i] = cand[i];
+                    // (T, cur) <- (Tn, cand): every thread swaps its pointers below instead of lane 0 copying 40 doubles
                     const double g = 2.0 * rho - 1.0;
                     sh.lambda *= fmax(1.0 / 3.0, fmin(1.0 - g * g * g, 2.0 / 3.0));
                     sh.ni = 2.0;
@@ -324,7 +323,11 @@ __device__ __forceinline__ int po_run(po_shared& sh, const double* points, const
             __syncthreads();
             int verdict = sh.flag;
             __syncthreads();                        // read before lane 0 overwrites it
-            if (verdict == 2) continue;
+            if (verdict == 2) {
+                double* t = cur; cur = cand; cand = t;
+                t = T; T = Tn; Tn = t;
+                continue;
+            }
             if (verdict == 3) break;
             // ---- trial 0 was turned down: the costs of trials 1..9 in one pass
             po_costs(sh.Tk, sh.solved_k, points, meas, active, O, cam, delta, red, part, sh.cost_k);
@@ -372,6 +375,11 @@ __device__ __forceinline__ int po_run(po_shared& sh, const double* points, const
         nactive = sh.nactive;
         __syncthreads();
         if (tid == 0) sh.nactive = 0;
+    }
+    if (T != sh.T) {                                    // the pointers may have ended up swapped: the kernel reads sh.T
+        __syncthreads();
+        if (tid < 12) sh.T[tid] = T[tid];
+        __syncthreads();
     }
     return nactive;
 }

@@ -36,7 +36,7 @@ def test_status_codes_and_messages(gpu_ctx):
     plan = (ctypes.c_int32 * 10)()
     assert lib.slam_bf_plan_info(ctx.handle, 65536, 65536, plan) == 0
     assert plan[0] == 1 and plan[1] == 256 and plan[4] % 32 == 0 and plan[3] >= 8 and plan[8] == 1   # long chunks: SGPR feed
-    assert lib.slam_bf_plan_info(ctx.handle, 200, 200, plan) == 0 and plan[4] == 0 and plan[8] == 0   # frame-sized: no leaders, LDS tile
+    assert lib.slam_bf_plan_info(ctx.handle, 200, 200, plan) == 0 and plan[4] == 0 and plan[9] == 128  # frame-sized: no leaders, unfiltered start
     assert lib.slam_bf_plan_info(ctx.handle, 0, 5, plan) == -1
     assert lib.slam_bf_reset_state(ctx.handle) == 0 and lib.slam_bf_reset_state(None) == -1
     # freeing a pointer the context does not own

@@ -97,10 +97,13 @@ def test_plan_tables_and_degenerate_inputs(gpu_ctx):
         assert p["lead_rows"] == 992 and p["lead_chunks"] == 11 and p["tail_chunks"] == 9 and p["chunks"] > 20
     finally:
         ctx.set_tuning()
-    # the feed follows the chunk length: SGPRs from 512 rows per chunk up, the LDS tile below (and for frame-sized calls)
+    # the feed follows the chunk length: SGPRs from 512 rows per chunk up and for chunks that fit the unfiltered start (rows
+    # in device memory, which is what plan_info assumes; rows in the pinned staging block of a host call take the LDS tile),
+    # the LDS tile in between
     assert ctx.plan_info(65536, 65536)["sgpr_feed"] == 1 and ctx.plan_info(1 << 20, 1 << 20)["sgpr_feed"] == 1
     assert ctx.plan_info(65536, 4096)["sgpr_feed"] == 1 and ctx.plan_info(8192, 65536)["sgpr_feed"] == 1
-    assert ctx.plan_info(4096, 4096)["sgpr_feed"] == 0 and ctx.plan_info(200, 200)["sgpr_feed"] == 0
+    assert ctx.plan_info(4096, 4096)["sgpr_feed"] == 1 and ctx.plan_info(200, 200)["sgpr_feed"] == 1
+    assert ctx.plan_info(8192, 8192)["sgpr_feed"] == 0 and ctx.plan_info(12000, 12000)["sgpr_feed"] == 0
     # small train sets: one block per CU up to 128 rows a chunk, about 8 sqrt(that) beyond; no tail up to two blocks per CU
     cus = ctx.plan_info(200, 200)["cus"]
     if cus == 256:
