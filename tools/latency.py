@@ -44,6 +44,34 @@ for _ in range(20):
     bf.knn_match_arrays(big_q, big_t, 2)
 dt = (time.perf_counter() - t0) / 20
 print(f"n= 65536 knn_match_arrays(k=2) on host buffers (PCIe inclusive) {dt * 1e3:8.3f} ms per call = {65536 * 65536 / dt:.3e} pairs/s")
+# BASELINE configs[1]: 4096 x 4096, knn = 2 + Lowe ratio test (0.75), one GPU - rows resident on the device (search + the
+# selection kernel between two events) and through the host-buffer call (4096 rows a side: zero-copy over PCIe)
+c1q, c1t = rng.integers(0, 256, (4096, 32), dtype=np.uint8), rng.integers(0, 256, (4096, 32), dtype=np.uint8)
+c1t[:40] = c1q[:40]                                   # some true matches, so that the ratio test keeps something
+_ctx = slamhip.default_context()
+_dq, _dt = slamhip.DeviceDescriptors(_ctx, c1q), slamhip.DeviceDescriptors(_ctx, c1t)
+_tab, _keep = slamhip.Top2Table(_ctx, 4096), _ctx.malloc(4096)
+import ctypes as _ct
+_cnt, _mind = _ct.c_int64(0), _ct.c_int32(0)
+def _dev():                                           # search + selection kernel + the count read back (one synchronisation)
+    slamhip.knn2_device(_ctx, _dq.buf, 4096, _dt.buf, 4096, _tab.idx, _tab.dist)
+    assert _ctx.lib.slam_bf_match_filter(_ctx.handle, _tab.idx.ptr, _tab.dist.ptr, 4096, 2, 0.75, _keep.ptr, _ct.byref(_cnt), _ct.byref(_mind)) == 0
+for _ in range(20):
+    _dev()
+t0 = time.perf_counter()
+for _ in range(200):
+    _dev()
+dev_us = (time.perf_counter() - t0) / 200 * 1e6
+for _ in range(5):
+    kept = slamhip.ratio_test_arrays(c1q, c1t, 0.75)
+t0 = time.perf_counter()
+for _ in range(50):
+    kept = slamhip.ratio_test_arrays(c1q, c1t, 0.75)
+print(f"n=  4096 knn=2 + ratio 0.75 (BASELINE configs[1]): {dev_us:6.1f} us per call with the rows resident (search, selection kernel, count read back) = "
+      f"{4096 * 4096 / dev_us * 1e6:.2e} pairs/s; ratio_test_arrays() on host buffers {(time.perf_counter() - t0) / 50 * 1e3:.3f} ms per call, "
+      f"{len(kept[0])} matches kept")
+for _o in (_dq, _dt, _tab, _keep):
+    _o.free()
 rm = slamhip.ResidentMatcher()
 fr = [rng.integers(0, 256, (200, 32), dtype=np.uint8) for _ in range(60)]
 rm.push(fr[0])
