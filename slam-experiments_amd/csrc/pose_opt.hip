@@ -242,127 +242,127 @@ __device__ __forceinline__ void po_costs(const double* Tk /*[PO_SPEC][12]*/, con
     po_block_sums<PO_SPEC>(acc, red, part, costs);
 }
 
+#define PO_TRIALS (PO_SPEC + 1)   // maxTrialsAfterFailure of g2o's Levenberg-Marquardt: ten trials per iteration
+
 struct po_shared {
     double red[PO_TERMS * PO_RED_STRIDE];
     double part[PO_TERMS * 8];
-    double cur[PO_TERMS], cand[PO_TERMS];
-    double T0[12], T[12], Tn[12];
-    double Tk[PO_SPEC * 12], scale_k[PO_SPEC], cost_k[PO_SPEC];   // the speculated trials of one iteration
-    int solved_k[PO_SPEC];
-    double lambda, ni;
-    int flag, accepted, nactive;
+    double sums[2][PO_TERMS];                       // the evaluation at the current pose / at the candidate: swapped, not copied
+    double T0[12], Tcur[12];
+    double pose[2][PO_TRIALS * 12];                 // the candidates of an iteration; the buffers alternate, so an accepted
+                                                    // candidate stays where it is and becomes the current pose by pointer
+    double scale_k[PO_TRIALS], cost_k[PO_SPEC];
+    int solved_k[PO_TRIALS];
+    int nactive;
 };
 
 // The LM loop proper.  Force-inlined into both call sites of the kernel so that the staged instance addresses
 // points / meas / active / chi2 as LDS (ds_read) and the large-problem instance as global memory, instead of
 // both going through flat loads on generic pointers.
+//
+// The Levenberg-Marquardt state (damping, its growth factor, the accepted-step count, which buffers hold the current
+// pose / sums / chi2) lives in REGISTERS of every thread: all threads read the same sums behind the same barrier and
+// take the same decision, so a verdict needs no lane-0 section and no barrier of its own (per iteration: one barrier
+// behind the proposals + the three of the evaluation; the first form had seven and two serial sections).
+// chi2_a / chi2_b: where evaluations leave e.e per edge.  With two buffers (the staged form) an evaluation writes the
+// one that is NOT current and an accepted pose makes it current by swapping the pointers, so the chi2 of the current pose
+// is always at hand and the outlier decision at the end of a round needs no evaluation of its own; with one buffer
+// (chi2_a == chi2_b: problems too large to stage) the round ends with an evaluation, as before.
 __device__ __forceinline__ int po_run(po_shared& sh, const double* points, const double2* meas, uint8_t* active,
-                                      double* chi2, int O, po_cam cam, po_params prm) {
+                                      double* chi2_a, double* chi2_b, int O, po_cam cam, po_params prm, int* accepted_out,
+                                      const double** pose_out, double** chi2_out) {
     const int tid = threadIdx.x;
-    double* red = sh.red; double* part = sh.part; double* cur = sh.cur; double* cand = sh.cand;
-    double* T0 = sh.T0; double* T = sh.T; double* Tn = sh.Tn;
+    double* red = sh.red; double* part = sh.part;
+    double* cur = sh.sums[0]; double* cand = sh.sums[1];
+    const double* T0 = sh.T0;
+    const double* T = sh.Tcur;
+    double* chi2 = chi2_a; double* chi2_w = chi2_b;          // current pose's / where the next evaluation writes
+    const bool two_chi2 = chi2_a != chi2_b;
+    int p = 0, accepted = 0;
     for (int o = tid; o < O; o += PO_THREADS) active[o] = 1;
     __syncthreads();
     int nactive = O;
     double delta = prm.huber_delta;
     for (int round = 0; round < prm.rounds; round++) {
-        if (tid < 12) T[tid] = T0[tid];                 // every round restarts from the frame's pose (frontend.py:360)
+        if (tid < 12) sh.Tcur[tid] = T0[tid];           // every round restarts from the frame's pose (frontend.py:360)
+        T = sh.Tcur;
         __syncthreads();
-        po_evaluate(T, points, meas, active, O, cam, delta, chi2, red, part, cur);
-        if (tid == 0) {
+        po_evaluate(T, points, meas, active, O, cam, delta, chi2_w, red, part, cur);
+        { double* t = chi2; chi2 = chi2_w; chi2_w = t; }
+        double lambda, ni = 2.0;
+        {
             double dmax = 0.0;
             const int diag[6] = {0, 6, 11, 15, 18, 20};
+#pragma unroll
             for (int i = 0; i < 6; i++) dmax = fmax(dmax, cur[diag[i]]);
-            sh.lambda = 1e-5 * fmax(dmax, 1e-12);        // tau * max diagonal
-            sh.ni = 2.0;
+            lambda = 1e-5 * fmax(dmax, 1e-12);          // tau * max diagonal
         }
-        __syncthreads();
         for (int it = 0; it < prm.iterations && nactive > 0; it++) {
             // ---- the ten trials of this iteration are PROPOSED together.  A trial that is turned down changes nothing but
             // the damping (lambda *= ni, ni *= 2), so the candidates of all ten trials are known in advance: lane j of
-            // wave 0 solves with the damping trial j would meet and builds its pose - ten solves for the latency of one.
-            // Trial 0 is then evaluated in full (cost, H, b); only when it is turned down does ONE more pass give the costs
-            // of trials 1..9, and lane 0 walks them in order: the first one the sequential loop would have accepted is
-            // accepted, with the damping that loop would have had.  g2o's schedule ends every round on ten rejected trials
-            // (maxTrialsAfterFailure): ten sequential solve + evaluation pairs (38 us of a 67 us round at 200 edges)
-            // become one solve and two passes.
-            if (tid <= PO_SPEC) {
-                double lam = sh.lambda, ni = sh.ni;
-                for (int k = 0; k < tid; k++) { lam *= ni; ni *= 2.0; }
+            // wave 0 solves with the damping trial j would meet and builds its pose - ten solves in the instruction stream
+            // of one.  Trial 0 is then evaluated in full (cost, H, b); only when it is turned down does ONE more pass give
+            // the costs of trials 1..9, and they are walked in order: the first one the sequential loop would have accepted
+            // is accepted, with the damping that loop would have had.  g2o's schedule ends every round on ten rejected
+            // trials (maxTrialsAfterFailure): ten sequential solve + evaluation pairs (38 us of a 67 us round at 200
+            // edges) become one solve and two passes.
+            double* cands = sh.pose[p];
+            if (tid < PO_TRIALS) {
+                double lam = lambda, n2 = ni;
+                for (int k = 0; k < tid; k++) { lam *= n2; n2 *= 2.0; }
                 double dx[6];
                 const bool ok_j = po_solve(cur, cur + 21, lam, dx);
                 double sc = 1e-3;
                 for (int i = 0; i < 6; i++) sc += dx[i] * (lam * dx[i] - cur[21 + i]);
-                // one instruction stream for all ten lanes: only the destinations differ
-                double* pose_j = tid == 0 ? Tn : sh.Tk + 12 * (tid - 1);
-                double* scale_j = tid == 0 ? cand : sh.scale_k + (tid - 1);          // cand[0]: parked until the evaluation overwrites cand
-                int* solved_j = tid == 0 ? &sh.flag : sh.solved_k + (tid - 1);
-                *solved_j = ok_j ? 1 : 0;
-                if (ok_j) { po_apply_update(dx, T, pose_j); *scale_j = sc; }
+                sh.solved_k[tid] = ok_j ? 1 : 0;
+                if (ok_j) { po_apply_update(dx, T, cands + 12 * tid); sh.scale_k[tid] = sc; }
             }
             __syncthreads();
-            const int solved = sh.flag;
-            const double scale = cand[0];
-            __syncthreads();                        // everybody has read sh.flag / cand[0] before lane 0 moves on
-            if (solved) po_evaluate(Tn, points, meas, active, O, cam, delta, chi2, red, part, cand);
-            if (tid == 0) {
-                const double rho = solved ? (cur[27] - cand[27]) / scale : -1.0;
-                if (solved && rho > 0.0 && isfinite(cand[27])) {
-                    // (T, cur) <- (Tn, cand): every thread swaps its pointers below instead of lane 0 copying 40 doubles
-                    const double g = 2.0 * rho - 1.0;
-                    sh.lambda *= fmax(1.0 / 3.0, fmin(1.0 - g * g * g, 2.0 / 3.0));
-                    sh.ni = 2.0;
-                    sh.accepted++;
-                    sh.flag = 2;
-                } else {
-                    sh.lambda *= sh.ni;
-                    sh.ni *= 2.0;
-                    sh.flag = (!solved || isfinite(sh.lambda)) ? 1 : 3;   // an unsolvable system never ends the iteration
-                }
-            }
-            __syncthreads();
-            int verdict = sh.flag;
-            __syncthreads();                        // read before lane 0 overwrites it
-            if (verdict == 2) {
-                double* t = cur; cur = cand; cand = t;
-                t = T; T = Tn; Tn = t;
+            const int solved = sh.solved_k[0];          // read now: the next iteration's proposals overwrite them
+            const double scale = sh.scale_k[0];
+            if (solved) po_evaluate(cands, points, meas, active, O, cam, delta, chi2_w, red, part, cand);
+            const double rho0 = solved ? (cur[27] - cand[27]) / scale : -1.0;
+            if (solved && rho0 > 0.0 && isfinite(cand[27])) {
+                { double* t = cur; cur = cand; cand = t; }
+                { double* t = chi2; chi2 = chi2_w; chi2_w = t; }
+                T = cands;
+                p ^= 1;
+                const double g = 2.0 * rho0 - 1.0;
+                lambda *= fmax(1.0 / 3.0, fmin(1.0 - g * g * g, 2.0 / 3.0));
+                ni = 2.0;
+                accepted++;
                 continue;
             }
-            if (verdict == 3) break;
+            lambda *= ni;
+            ni *= 2.0;
+            if (solved && !isfinite(lambda)) break;     // (an unsolvable system never ends the iteration by itself)
             // ---- trial 0 was turned down: the costs of trials 1..9 in one pass
-            po_costs(sh.Tk, sh.solved_k, points, meas, active, O, cam, delta, red, part, sh.cost_k);
-            if (tid == 0) {
-                double lam = sh.lambda, ni = sh.ni;
-                int v = 1;
-                for (int j = 0; j < PO_SPEC; j++) {
-                    if (sh.solved_k[j]) {
-                        const double rho = (cur[27] - sh.cost_k[j]) / sh.scale_k[j];
-                        if (rho > 0.0 && isfinite(sh.cost_k[j])) {
-                            for (int i = 0; i < 12; i++) T[i] = sh.Tk[12 * j + i];
-                            const double g = 2.0 * rho - 1.0;
-                            lam *= fmax(1.0 / 3.0, fmin(1.0 - g * g * g, 2.0 / 3.0));
-                            ni = 2.0;
-                            sh.accepted++;
-                            v = 2;
-                            break;
-                        }
+            po_costs(cands + 12, sh.solved_k + 1, points, meas, active, O, cam, delta, red, part, sh.cost_k);
+            int taken = -1;
+            for (int j = 0; j < PO_SPEC; j++) {
+                if (sh.solved_k[j + 1]) {
+                    const double rho = (cur[27] - sh.cost_k[j]) / sh.scale_k[j + 1];
+                    if (rho > 0.0 && isfinite(sh.cost_k[j])) {
+                        const double g = 2.0 * rho - 1.0;
+                        lambda *= fmax(1.0 / 3.0, fmin(1.0 - g * g * g, 2.0 / 3.0));
+                        ni = 2.0;
+                        taken = j + 1;
+                        break;
                     }
-                    lam *= ni;
-                    ni *= 2.0;
-                    if (sh.solved_k[j] && !isfinite(lam)) { v = 3; break; }
                 }
-                sh.lambda = lam;
-                sh.ni = ni;
-                sh.flag = v;
+                lambda *= ni;
+                ni *= 2.0;
+                if (sh.solved_k[j + 1] && !isfinite(lambda)) break;
             }
-            __syncthreads();
-            verdict = sh.flag;
-            __syncthreads();
-            if (verdict != 2) break;                // ten trials turned down (or the damping overflowed): the round's iterations end
-            po_evaluate(T, points, meas, active, O, cam, delta, chi2, red, part, cur);   // H, b, cost at the accepted pose
+            if (taken < 0) break;                       // ten trials turned down (or the damping overflowed): the round's iterations end
+            accepted++;
+            T = cands + 12 * taken;
+            p ^= 1;
+            po_evaluate(T, points, meas, active, O, cam, delta, chi2_w, red, part, cur);   // H, b, cost at the accepted pose
+            { double* t = chi2; chi2 = chi2_w; chi2_w = t; }
         }
         // chi2 at the pose this round ended on, then the outlier / level decision (frontend.py:366-379)
-        po_evaluate(T, points, meas, active, O, cam, delta, chi2, red, part, cand);
+        if (!two_chi2) po_evaluate(T, points, meas, active, O, cam, delta, chi2, red, part, cand);
         int mine = 0;
         for (int o = tid; o < O; o += PO_THREADS) {
             const uint8_t in = chi2[o] <= prm.chi2_threshold ? 1 : 0;
@@ -376,11 +376,9 @@ __device__ __forceinline__ int po_run(po_shared& sh, const double* points, const
         __syncthreads();
         if (tid == 0) sh.nactive = 0;
     }
-    if (T != sh.T) {                                    // the pointers may have ended up swapped: the kernel reads sh.T
-        __syncthreads();
-        if (tid < 12) sh.T[tid] = T[tid];
-        __syncthreads();
-    }
+    *accepted_out = accepted;
+    *pose_out = T;
+    *chi2_out = chi2;
     return nactive;
 }
 
@@ -409,25 +407,31 @@ __global__ __launch_bounds__(PO_THREADS) void pose_opt_kernel(const double* __re
     // global memory.  Larger problems run the same code on the global arrays.
     __shared__ double s_points[PO_STAGE * 3];
     __shared__ double2 s_meas[PO_STAGE];
-    __shared__ double s_chi2[PO_STAGE];
+    __shared__ double s_chi2[2][PO_STAGE];
     __shared__ uint8_t s_active[PO_STAGE];
     __shared__ po_shared sh;
     const int tid = threadIdx.x;
-    if (tid < 12) sh.T0[tid] = sh.T[tid] = pose_in[tid];
-    if (tid == 0) { sh.accepted = 0; sh.nactive = 0; }
-    int nactive;
+    if (tid < 12) sh.T0[tid] = sh.Tcur[tid] = pose_in[tid];
+    if (tid == 0) sh.nactive = 0;
+    int nactive, accepted = 0;
+    const double* pose = sh.Tcur;
+    double* chi2 = nullptr;
     if (O <= PO_STAGE) {
         for (int i = tid; i < O * 3; i += PO_THREADS) s_points[i] = g_points[i];
         for (int o = tid; o < O; o += PO_THREADS) s_meas[o] = g_meas[o];
-        nactive = po_run(sh, s_points, s_meas, s_active, s_chi2, O, cam, prm);
-        for (int o = tid; o < O; o += PO_THREADS) { g_active[o] = s_active[o]; g_chi2[o] = s_chi2[o]; }
+        nactive = po_run(sh, s_points, s_meas, s_active, s_chi2[0], s_chi2[1], O, cam, prm, &accepted, &pose, &chi2);
+        if (prm.rounds > 0)
+            for (int o = tid; o < O; o += PO_THREADS) { g_active[o] = s_active[o]; g_chi2[o] = chi2[o]; }
+        else
+            for (int o = tid; o < O; o += PO_THREADS) { g_active[o] = 1; g_chi2[o] = 0.0; }
     } else {
-        nactive = po_run(sh, g_points, g_meas, g_active, g_chi2, O, cam, prm);
+        nactive = po_run(sh, g_points, g_meas, g_active, g_chi2, g_chi2, O, cam, prm, &accepted, &pose, &chi2);
     }
-    if (tid < 12) pose_out[tid] = sh.T[tid];
+    __syncthreads();
+    if (tid < 12) pose_out[tid] = pose[tid];
     if (tid == 0) {
         stats[0] = prm.rounds > 0 ? nactive : O;   // inlier count: what _correct_current_pose returns (frontend.py:393)
-        stats[1] = sh.accepted;                     // accepted LM steps over all rounds
+        stats[1] = accepted;                        // accepted LM steps over all rounds
     }
 }
 
