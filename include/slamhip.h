@@ -156,6 +156,15 @@ SLAM_API int slam_bf_set_tuning(slam_ctx* ctx, const int32_t* h_knobs, int count
  * {R, query blocks, uniform chunk rows, chunks, leader rows, leader chunks, shrinking tail chunks, CUs,
  *  feed (1 = train rows through SGPRs, 0 = through an LDS tile), unfiltered rows at a cold chunk start}. */
 SLAM_API int slam_bf_plan_info(slam_ctx* ctx, int64_t N, int64_t M, int32_t* h_plan);
+/* The same plan WITHOUT a device: a pure function of the CU count, the knobs (as slam_bf_set_tuning; NULL / 0 = shipped)
+ * and the shape, so that the planner can be held to its invariants on a host without a GPU.  h_plan int32 [12] =
+ * slam_bf_plan_info's ten entries (h_plan[7] = num_cu) + {table-free: the kernel computes its chunk from the block index
+ * and no boundary table is uploaded, bound-free: no block reads or writes a bound}.  The chunk boundary table (chunks + 1
+ * ascending row indices from 0 to M) goes to h_tbl (up to tbl_cap entries; may be NULL) and its length to *tbl_len.
+ * rows_on_host: the train rows lie in pinned host memory (frame-sized host calls).  qb_all: the query blocks of all the
+ * searches that share the launch (slam_bf_knn2_batch_u256), 0 for a search that has the grid to itself. */
+SLAM_API int slam_bf_plan_describe(int num_cu, const int32_t* h_knobs, int count, int64_t N, int64_t M, int64_t qb_all,
+                                   int rows_on_host, int32_t* h_plan, int32_t* h_tbl, int64_t tbl_cap, int64_t* tbl_len);
 /* Restore the matcher's per-context merge state to its idle values.  Every search leaves it clean by itself;
  * call this after a search failed part-way (the library does so on a failed launch).  Stream-ordered. */
 SLAM_API int slam_bf_reset_state(slam_ctx* ctx);

@@ -607,12 +607,7 @@ struct bf_plan {
     int uni;         // > 0: every chunk has this many rows (no leaders, no tail) and the kernel needs no boundary table
 };
 
-// Tuning overrides live in the context (0 = heuristic): set through slam_bf_set_tuning, read under ctx->mu.
-extern "C" int slam_bf_set_tuning(slam_ctx* ctx, const int32_t* h_knobs, int count) {
-    SLAM_REQUIRE(ctx, "slam_bf_set_tuning: null ctx");
-    SLAM_REQUIRE(count >= 0 && count <= SLAM_BF_KNOBS && (h_knobs || count == 0), "bad knob array");
-    int k[SLAM_BF_KNOBS] = {};
-    for (int i = 0; i < count; i++) k[i] = h_knobs[i];
+static int bf_check_knobs(const int* k) {
     SLAM_REQUIRE(k[0] == 0 || k[0] == 1 || k[0] == 2 || k[0] == 4 || k[0] == 8, "R must be 0, 1, 2, 4 or 8");
     SLAM_REQUIRE(k[1] >= 0 && k[1] <= 64, "blocks_per_cu out of range");
     SLAM_REQUIRE(k[2] >= -1 && k[2] <= (1 << 22), "lead_rows out of range");
@@ -622,6 +617,16 @@ extern "C" int slam_bf_set_tuning(slam_ctx* ctx, const int32_t* h_knobs, int cou
     SLAM_REQUIRE(!(k[5] == 1 && k[0] > 1), "the SGPR-fed scan holds one query per lane (R = 1)");
     SLAM_REQUIRE(k[6] >= -1 && k[6] <= (1 << 20) && (k[6] < 0 || k[6] % 16 == 0), "cold must be -1 or a multiple of 16 rows");
     SLAM_REQUIRE(k[7] >= 0 && k[7] <= (1 << 22) && k[7] % 32 == 0, "chunk must be a multiple of 32 rows");
+    return SLAM_OK;
+}
+
+// Tuning overrides live in the context (0 = heuristic): set through slam_bf_set_tuning, read under ctx->mu.
+extern "C" int slam_bf_set_tuning(slam_ctx* ctx, const int32_t* h_knobs, int count) {
+    SLAM_REQUIRE(ctx, "slam_bf_set_tuning: null ctx");
+    SLAM_REQUIRE(count >= 0 && count <= SLAM_BF_KNOBS && (h_knobs || count == 0), "bad knob array");
+    int k[SLAM_BF_KNOBS] = {};
+    for (int i = 0; i < count; i++) k[i] = h_knobs[i];
+    if (int rc = bf_check_knobs(k)) return rc;
     std::lock_guard<std::mutex> g(ctx->mu);
     for (int i = 0; i < SLAM_BF_KNOBS; i++) ctx->bf_knob[i] = k[i];
     return SLAM_OK;
@@ -629,7 +634,7 @@ extern "C" int slam_bf_set_tuning(slam_ctx* ctx, const int32_t* h_knobs, int cou
 
 // uniform chunks of the rows [0, M) for a given R: aim at `blocks_per_cu` blocks per CU, a chunk being at least one LDS tile.
 // qb_all: the query blocks of ALL searches that share the launch (a batch), or 0 for a search that has the grid to itself.
-static void plan_uniform(const slam_ctx* ctx, int64_t N, int64_t M, int R, int blocks_per_cu, bool forced, int64_t qb_all,
+static void plan_uniform(int num_cu, const int* knob, int64_t N, int64_t M, int R, int blocks_per_cu, bool forced, int64_t qb_all,
                          bf_plan* p) {
     const int64_t tiles = (M + SLAM_TILE_ROWS - 1) / SLAM_TILE_ROWS;
     p->R = R;
@@ -641,8 +646,8 @@ static void plan_uniform(const slam_ctx* ctx, int64_t N, int64_t M, int R, int b
     // travel through SGPRs from 512 rows per chunk up (round 2's LDS-only kernel preferred 64 here):
     // 24 measured best over 8192 / 16384 / 32768 x 65536 and 8192 x 2^20 (profiles/r03_shard_plan_sweep.log:
     // the 1/8 shard of the 64k x 64k grid 187 -> 174 us, 16384 x 65536 334 -> 296 us).
-    if (!blocks_per_cu) blocks_per_cu = p->qblocks >= ctx->num_cu ? 32 : 24;
-    int64_t S = (int64_t)ctx->num_cu * blocks_per_cu / qb_all;
+    if (!blocks_per_cu) blocks_per_cu = p->qblocks >= num_cu ? 32 : 24;
+    int64_t S = (int64_t)num_cu * blocks_per_cu / qb_all;
     if (S > tiles) S = tiles;
     if (S < 1) S = 1;
     int64_t chunk = (M + S - 1) / S;
@@ -657,7 +662,7 @@ static void plan_uniform(const slam_ctx* ctx, int64_t N, int64_t M, int R, int b
         // to 128 rows (frame-sized searches, the reference matches <= 200 x 200, slam.py:23: 32-64 rows per block) and
         // about 8 sqrt(c1) beyond - 4096 x 4096: 128 rows (2 blocks per CU, 23.0 -> 17.6 us), 8192 x 8192: 256 (4 per CU,
         // 40.2 -> 33.0 us), 12000 x 12000: 384, 65536 x 4096 and sixteen 4096 x 4096 in one launch: 512 (8 per CU).
-        int64_t c1 = (M * qb_all + ctx->num_cu - 1) / ctx->num_cu;
+        int64_t c1 = (M * qb_all + num_cu - 1) / num_cu;
         int64_t c2 = c1;
         if (c1 > 128) {
             int64_t r = 1;
@@ -666,7 +671,7 @@ static void plan_uniform(const slam_ctx* ctx, int64_t N, int64_t M, int R, int b
         }
         c2 = (c2 + 31) / 32 * 32;
         chunk = c2 < 32 ? 32 : (c2 > 512 ? 512 : c2);
-        if (ctx->bf_knob[7]) chunk = ctx->bf_knob[7];
+        if (knob[7]) chunk = knob[7];
     }
     p->chunk = (int)chunk;
 }
@@ -686,15 +691,15 @@ static bool bf_rows_on_host(const slam_ctx* ctx, const void* p) {
     return ctx->io_host && c >= (const char*)ctx->io_host && c < (const char*)ctx->io_host + ctx->io_host_bytes;
 }
 
-static bf_plan make_plan(slam_ctx* ctx, int64_t N, int64_t M, std::vector<int>* tbl, int64_t qb_all = 0,
-                         bool rows_on_host = false) {
-    std::lock_guard<std::mutex> g(ctx->mu);
-    const int* k = ctx->bf_knob;
+// The planner proper: a pure function of the device's CU count, the knobs and the shape (slam_bf_plan_describe exposes it
+// without a device, so the CPU test suite can hold it to its invariants).
+static bf_plan make_plan_core(int num_cu, const int* k, int64_t N, int64_t M, std::vector<int>* tbl, int64_t qb_all,
+                              bool rows_on_host) {
     bf_plan p;
     // R = 1 query per lane measured fastest at every size tried (64k x 64k: 1.68 ms vs 1.79 ms for R = 2,
     // 1.96 ms for R = 4; 58 VGPRs, 8 waves/SIMD); R = 2 / 4 / 8 stay available through slam_bf_set_tuning.
-    plan_uniform(ctx, N, M, k[0] ? k[0] : 1, k[1], k[1] != 0, qb_all, &p);
-    const int64_t slots = (int64_t)ctx->num_cu * 8;                      // resident blocks of 4 waves at 8 waves/SIMD
+    plan_uniform(num_cu, k, N, M, k[0] ? k[0] : 1, k[1], k[1] != 0, qb_all, &p);
+    const int64_t slots = (int64_t)num_cu * 8;                      // resident blocks of 4 waves at 8 waves/SIMD
     // ---- leaders
     int64_t lead_rows = k[2] < 0 ? 0 : k[2];
     if (k[2] == 0 && M >= 16384) {
@@ -708,7 +713,7 @@ static bf_plan make_plan(slam_ctx* ctx, int64_t N, int64_t M, std::vector<int>* 
     int64_t lead_chunk = k[3];
     if (lead_rows && !lead_chunk) {
         // about one leader wave per SIMD (one block per CU) across all query blocks, chunks of at least 128 rows
-        int64_t per_q = (ctx->num_cu + p.qblocks - 1) / p.qblocks;
+        int64_t per_q = (num_cu + p.qblocks - 1) / p.qblocks;
         if (per_q > lead_rows / 128) per_q = lead_rows / 128;
         if (per_q < 1) per_q = 1;
         lead_chunk = (lead_rows / per_q + 31) / 32 * 32;
@@ -730,7 +735,7 @@ static bf_plan make_plan(slam_ctx* ctx, int64_t N, int64_t M, std::vector<int>* 
     // table; fuller one-round grids are dispatched over a longer time and keep it: 12000 x 12000 61 -> 57 us)
     const int64_t qb_launch = qb_all > p.qblocks ? qb_all : p.qblocks;
     const bool one_round = lead_rows == 0 && qb_launch * n_uniform <= slots;
-    if (one_round && qb_launch * n_uniform <= 2 * (int64_t)ctx->num_cu && k[4] == 0) tail = 0;
+    if (one_round && qb_launch * n_uniform <= 2 * (int64_t)num_cu && k[4] == 0) tail = 0;
     std::vector<int>& b = *tbl;
     b.clear();
     b.push_back(0);
@@ -775,8 +780,38 @@ static bf_plan make_plan(slam_ctx* ctx, int64_t N, int64_t M, std::vector<int>* 
     p.cold = k[6] < 0 ? 0 : (k[6] ? k[6] : SLAM_COLD_ROWS);
     p.uni = p.tail == 0 && p.lead == 0 ? p.chunk : 0;
     // one round and no chunk longer than the unfiltered start: the kernel exchanges no bounds at all (passed as -cold)
-    if (one_round && p.chunk <= p.cold && p.lead == 0) p.cold = -p.cold;
+    if (qb_launch * (int64_t)p.S <= slots && p.chunk <= p.cold && p.lead == 0) p.cold = -p.cold;   // (S: the tail's extra chunks counted)
     return p;
+}
+
+static bf_plan make_plan(slam_ctx* ctx, int64_t N, int64_t M, std::vector<int>* tbl, int64_t qb_all = 0,
+                         bool rows_on_host = false) {
+    std::lock_guard<std::mutex> g(ctx->mu);
+    return make_plan_core(ctx->num_cu, ctx->bf_knob, N, M, tbl, qb_all, rows_on_host);
+}
+
+// The launch plan for N x M on a device with `num_cu` CUs under `count` knobs (as slam_bf_set_tuning; NULL / 0 = shipped),
+// WITHOUT a device: h_plan int32 [12] = slam_bf_plan_info's ten entries (h_plan[7] = num_cu) + {table-free (1 = the kernel
+// computes its chunk from the block index), bound-free (1 = no block reads or writes a bound)}; the chunk boundary table
+// goes to h_tbl (up to tbl_cap entries; may be NULL) and its length to *tbl_len.  rows_on_host: the train rows lie in
+// pinned host memory (frame-sized host calls).  qb_all: query blocks of all searches sharing the launch (0 = alone).
+extern "C" int slam_bf_plan_describe(int num_cu, const int32_t* h_knobs, int count, int64_t N, int64_t M, int64_t qb_all,
+                                     int rows_on_host, int32_t* h_plan, int32_t* h_tbl, int64_t tbl_cap, int64_t* tbl_len) {
+    SLAM_REQUIRE(num_cu >= 1 && num_cu <= 4096, "num_cu out of range");
+    SLAM_REQUIRE(count >= 0 && count <= SLAM_BF_KNOBS && (h_knobs || count == 0), "bad knob array");
+    SLAM_REQUIRE(N >= 1 && M >= 1 && M <= SLAM_MAX_TRAIN_PER_PASS && N <= (1ll << 30) && qb_all >= 0, "bad sizes");
+    SLAM_REQUIRE(h_plan && tbl_len && (h_tbl || tbl_cap == 0) && tbl_cap >= 0, "slam_bf_plan_describe: null argument");
+    int k[SLAM_BF_KNOBS] = {};
+    for (int i = 0; i < count; i++) k[i] = h_knobs[i];
+    if (int rc = bf_check_knobs(k)) return rc;
+    std::vector<int> tbl;
+    const bf_plan p = make_plan_core(num_cu, k, N, M, &tbl, qb_all, rows_on_host != 0);
+    h_plan[0] = p.R; h_plan[1] = p.qblocks; h_plan[2] = p.chunk; h_plan[3] = p.S;
+    h_plan[4] = p.lead_rows; h_plan[5] = p.lead; h_plan[6] = p.tail; h_plan[7] = num_cu;
+    h_plan[8] = p.sfeed; h_plan[9] = p.cold < 0 ? -p.cold : p.cold; h_plan[10] = p.uni ? 1 : 0; h_plan[11] = p.cold < 0 ? 1 : 0;
+    *tbl_len = (int64_t)tbl.size();
+    for (int64_t i = 0; i < (int64_t)tbl.size() && i < tbl_cap; i++) h_tbl[i] = tbl[(size_t)i];
+    return SLAM_OK;
 }
 
 extern "C" int slam_bf_plan_info(slam_ctx* ctx, int64_t N, int64_t M, int32_t* h_plan /*[10]*/) {

@@ -122,3 +122,24 @@ def default_context() -> Context:
         if _default_ctx is None:
             _default_ctx = Context(0)
         return _default_ctx
+
+
+PLAN_KNOBS = ("R", "blocks_per_cu", "lead_rows", "lead_chunk", "tail", "feed", "cold", "chunk")
+
+
+def plan_describe(n: int, m: int, num_cu: int = 256, qb_all: int = 0, rows_on_host: bool = False, **knobs):
+    """The launch plan of the top-2 search for n x m on a device with ``num_cu`` CUs, WITHOUT a device
+    (``slam_bf_plan_describe``): (plan dict, chunk boundary table).  ``knobs``: as ``Context.set_tuning``."""
+    unknown = set(knobs) - set(PLAN_KNOBS)
+    if unknown:
+        raise TypeError(f"unknown knobs {sorted(unknown)}")
+    lib = _lib.load()
+    k = (ctypes.c_int32 * len(PLAN_KNOBS))(*(int(knobs.get(name, 0)) for name in PLAN_KNOBS))
+    plan = (ctypes.c_int32 * 12)()
+    cap = 1 << 16
+    tbl = (ctypes.c_int32 * cap)()
+    length = ctypes.c_int64(0)
+    check(lib.slam_bf_plan_describe(num_cu, k, len(PLAN_KNOBS), n, m, qb_all, int(rows_on_host), plan, tbl, cap, ctypes.byref(length)))
+    names = ("R", "qblocks", "chunk", "chunks", "lead_rows", "lead_chunks", "tail_chunks", "cus", "sgpr_feed", "cold_rows",
+             "table_free", "bound_free")
+    return dict(zip(names, plan)), list(tbl[:min(length.value, cap)])

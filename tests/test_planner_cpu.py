@@ -1,0 +1,101 @@
+"""CPU suite: the launch planner of the top-2 search as a pure function (slam_bf_plan_describe needs no device) - the
+chunk boundary table covers the train rows exactly under every knob setting, and the shipped rules are the measured ones
+(leaders from 16384 rows up, one block per CU up to 128 rows a chunk and about 8 sqrt(that) beyond,
+no tail and no table for grids of up to two blocks per CU, no bound exchange when every chunk fits its unfiltered start,
+SGPR feed for long and for short chunks but never for rows in pinned host memory)."""
+import itertools
+
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def plan(built):
+    import slamhip
+
+    return slamhip.plan_describe
+
+
+def _check_table(p, tbl, m):
+    assert len(tbl) == p["chunks"] + 1 and tbl[0] == 0 and tbl[-1] == m, (p, tbl[:4], tbl[-4:])
+    steps = np.diff(tbl)
+    assert (steps > 0).all(), "every chunk holds at least one row"
+    if p["lead_chunks"]:
+        assert tbl[p["lead_chunks"]] == p["lead_rows"]
+    if p["tail_chunks"]:
+        tail = steps[-p["tail_chunks"]:]
+        assert (np.diff(tail[:-1]) <= 0).all(), "the tail shrinks"           # (the very last chunk takes the remainder)
+    if p["table_free"]:
+        assert p["lead_chunks"] == 0 and p["tail_chunks"] == 0
+        assert (steps[:-1] == p["chunk"]).all() and steps[-1] <= p["chunk"], "a table-free plan is by * chunk"
+    if p["bound_free"]:
+        assert steps.max() <= p["cold_rows"] and p["lead_chunks"] == 0
+        assert p["qblocks"] * p["chunks"] <= p["cus"] * 8, "only grids that are resident all at once go without bounds"
+
+
+def test_tables_cover_the_train_rows_under_any_knobs(plan):
+    rng = np.random.default_rng(5)
+    shapes = [(1, 1), (200, 200), (1, 70000), (257, 769), (4096, 4096), (5000, 16383), (5000, 16384), (8192, 65536),
+              (65536, 65536), (70, 1 << 20), (1 << 20, 1 << 20), (3, (1 << 23))]
+    shapes += [(int(rng.integers(1, 9000)), int(rng.integers(1, 300000))) for _ in range(40)]
+    for n, m in shapes:
+        for cus in (256, 304, 8):
+            p, tbl = plan(n, m, num_cu=cus)
+            _check_table(p, tbl, m)
+            assert p["R"] == 1 and p["qblocks"] == (n + 255) // 256 and p["cus"] == cus
+    knob_sets = itertools.product((0, 2), (0, 1, 16, 64), (0, -1, 256, 4096), (0, 64), (0, -1, 5, 64), (0, -1), (0, -1, 16, 1024), (0, 96, 512))
+    for (R, bpc, lead, lchunk, tail, feed, cold, chunk), (n, m) in zip(knob_sets, itertools.cycle(shapes[1:20])):
+        p, tbl = plan(n, m, R=R, blocks_per_cu=bpc, lead_rows=lead, lead_chunk=lchunk, tail=tail, feed=feed, cold=cold, chunk=chunk)
+        _check_table(p, tbl, m)
+        assert p["R"] == (R or 1) and (p["sgpr_feed"] == 0 or p["R"] == 1)
+        if cold == -1:
+            assert p["cold_rows"] == 0 and not p["bound_free"]
+        if lead == -1:
+            assert p["lead_chunks"] == 0
+        if tail == -1:
+            assert p["tail_chunks"] == 0
+
+
+def test_shipped_rules_on_a_256_cu_device(plan):
+    # leaders: M / 8 up to 8192 rows from 16384 train rows up, none below
+    for m, lead in ((200, 0), (16383, 0), (16384, 2048), (65536, 8192), (1 << 20, 8192)):
+        p, _ = plan(8192, m)
+        assert p["lead_rows"] == lead and (p["lead_chunks"] > 0) == (lead > 0), (m, p)
+    # small train sets: one block per CU up to 128 rows a chunk, about 8 sqrt(that) beyond, at most 512
+    for (n, m), chunk in (((200, 200), 32), ((1000, 1000), 32), ((2000, 2000), 64), ((4096, 4096), 128), ((8192, 8192), 256),
+                          ((12000, 12000), 384), ((65536, 4096), 512)):
+        p, _ = plan(n, m)
+        assert p["chunk"] == chunk and p["cold_rows"] == 128 and p["lead_rows"] == 0, (n, m, p)
+    # sixteen 4096 x 4096 searches in one launch plan their chunks for the whole grid
+    assert plan(4096, 4096, qb_all=256)[0]["chunk"] == 512
+    # up to two blocks per CU: uniform chunks, no table; with every chunk inside the unfiltered start also no bounds
+    for n, m in ((200, 200), (1000, 1000), (3000, 3000), (4096, 4096)):
+        p, _ = plan(n, m)
+        assert p["table_free"] and p["bound_free"] and p["tail_chunks"] == 0, (n, m, p)
+    p, _ = plan(12000, 12000)
+    assert not p["table_free"] and not p["bound_free"] and p["tail_chunks"] > 0
+    p, _ = plan(65536, 65536)
+    assert not p["table_free"] and not p["bound_free"] and p["chunk"] == 2048 and p["lead_chunks"] == 1 and p["tail_chunks"] == 8
+    # the feed: SGPRs for chunks of >= 512 rows and for chunks inside the unfiltered start, the LDS tile in between -
+    # and always for rows that lie in pinned host memory unless the chunks are long (those rows were copied to the device)
+    assert plan(65536, 65536)[0]["sgpr_feed"] == 1 and plan(8192, 65536)[0]["sgpr_feed"] == 1
+    assert plan(4096, 4096)[0]["sgpr_feed"] == 1 and plan(200, 200)[0]["sgpr_feed"] == 1
+    assert plan(8192, 8192)[0]["sgpr_feed"] == 0 and plan(12000, 12000)[0]["sgpr_feed"] == 0
+    assert plan(4096, 4096, rows_on_host=True)[0]["sgpr_feed"] == 0 and plan(200, 200, rows_on_host=True)[0]["sgpr_feed"] == 0
+    # query shards (fewer query blocks than CUs) plan 24 blocks per CU: the 1/8 shard of the headline grid
+    p, _ = plan(8192, 65536)
+    assert p["chunk"] == 512 and p["qblocks"] == 32
+
+
+def test_bad_arguments_are_refused(plan):
+    import slamhip
+
+    for kw in (dict(R=3), dict(lead_chunk=48), dict(cold=24), dict(chunk=100), dict(feed=2), dict(R=2, feed=1)):
+        with pytest.raises(slamhip.SlamHipError):
+            plan(1000, 1000, **kw)
+    with pytest.raises(slamhip.SlamHipError):
+        plan(0, 10)
+    with pytest.raises(slamhip.SlamHipError):
+        plan(10, (1 << 23) + 1)
+    with pytest.raises(TypeError):
+        plan(10, 10, nonsense=1)
