@@ -640,13 +640,16 @@ static void plan_uniform(int num_cu, const int* knob, int64_t N, int64_t M, int 
     p->R = R;
     p->qblocks = (int)((N + 256 * R - 1) / (256 * R));
     if (qb_all < p->qblocks) qb_all = p->qblocks;
-    // 32 blocks per CU = 4 rounds at 8 waves/SIMD: finished waves keep being replaced, so the
-    // under-occupied tail (a lone wave per SIMD issues at under half rate) is short.  Query shards
-    // with fewer query blocks than CUs (multi-GPU runs) want FEWER, longer chunks since the train rows
-    // travel through SGPRs from 512 rows per chunk up (round 2's LDS-only kernel preferred 64 here):
-    // 24 measured best over 8192 / 16384 / 32768 x 65536 and 8192 x 2^20 (profiles/r03_shard_plan_sweep.log:
-    // the 1/8 shard of the 64k x 64k grid 187 -> 174 us, 16384 x 65536 334 -> 296 us).
-    if (!blocks_per_cu) blocks_per_cu = p->qblocks >= num_cu ? 32 : 24;
+    // Blocks per CU.  Round 2's LDS-only kernel wanted many short chunks (32-64 blocks per CU: finished waves keep being
+    // replaced, so the under-occupied tail is short).  The SGPR-fed scan prefers FEWER, longer chunks - every chunk costs a
+    // start without a threshold, a merge and a ticket, and the shrinking tail takes care of the drain: swept again on the
+    // final kernel (profiles/r03_blocks_per_cu_sweep.log), 12-18 blocks per CU are best or equal from the 1/8 shard to
+    // the headline grid as long as there are no more query blocks than CUs; 16 ships (64k x 64k 1072 -> 1058 us against
+    // 32; 8192 x 65536 153.8 -> 151.2 us against 24; 49152 x 49152 620.8 -> 614.6 us; 32768 x 32768, 20000 x 20000,
+    // 50000 x 20000 equal; 40000 x 40000 +0.8 %; 14 is worth another 0.1 % at 64k x 64k and costs 2 % at 50000 x 20000).
+    // Above that every block already scans tens of thousands of rows and 32 stays (2^20 x 131072: 33.0 ms against
+    // 34.7 ms at anything lower).
+    if (!blocks_per_cu) blocks_per_cu = p->qblocks > num_cu ? 32 : 16;
     int64_t S = (int64_t)num_cu * blocks_per_cu / qb_all;
     if (S > tiles) S = tiles;
     if (S < 1) S = 1;
@@ -723,7 +726,8 @@ static bf_plan make_plan_core(int num_cu, const int* k, int64_t N, int64_t M, st
     // ---- tail
     const int64_t rest = M - lead_rows;
     int64_t n_uniform = (rest + p.chunk - 1) / p.chunk;
-    int64_t tail = k[4] < 0 ? 0 : (k[4] ? k[4] : 16);                    // shipped: 16 (8 / 16 / 32 measured alike, 4 worse)
+    int64_t tail = k[4] < 0 ? 0 : (k[4] ? k[4] : 32);                    // shipped: 32 (round 2: 16; with 14 blocks per CU 32 is
+                                                                          // worth 2 % on the 1/8 shard and equal elsewhere)
     if (tail > 0) {
         const int64_t last_round = (slots + p.qblocks - 1) / p.qblocks;  // chunk indices in flight when the grid drains
         if (tail > last_round) tail = last_round;

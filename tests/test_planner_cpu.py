@@ -75,16 +75,18 @@ def test_shipped_rules_on_a_256_cu_device(plan):
     p, _ = plan(12000, 12000)
     assert not p["table_free"] and not p["bound_free"] and p["tail_chunks"] > 0
     p, _ = plan(65536, 65536)
-    assert not p["table_free"] and not p["bound_free"] and p["chunk"] == 2048 and p["lead_chunks"] == 1 and p["tail_chunks"] == 8
+    assert not p["table_free"] and not p["bound_free"] and p["chunk"] == 4096 and p["lead_chunks"] == 1 and p["chunks"] == 19   # 16 blocks per CU
     # the feed: SGPRs for chunks of >= 512 rows and for chunks inside the unfiltered start, the LDS tile in between -
     # and always for rows that lie in pinned host memory unless the chunks are long (those rows were copied to the device)
     assert plan(65536, 65536)[0]["sgpr_feed"] == 1 and plan(8192, 65536)[0]["sgpr_feed"] == 1
     assert plan(4096, 4096)[0]["sgpr_feed"] == 1 and plan(200, 200)[0]["sgpr_feed"] == 1
     assert plan(8192, 8192)[0]["sgpr_feed"] == 0 and plan(12000, 12000)[0]["sgpr_feed"] == 0
     assert plan(4096, 4096, rows_on_host=True)[0]["sgpr_feed"] == 0 and plan(200, 200, rows_on_host=True)[0]["sgpr_feed"] == 0
-    # query shards (fewer query blocks than CUs) plan 24 blocks per CU: the 1/8 shard of the headline grid
+    # no more query blocks than CUs: 16 blocks per CU and up to 32 shrinking chunks at the end (the 1/8 shard of the headline
+    # grid); more query blocks than CUs: 32 blocks per CU
     p, _ = plan(8192, 65536)
-    assert p["chunk"] == 512 and p["qblocks"] == 32
+    assert p["chunk"] == 512 and p["qblocks"] == 32 and p["tail_chunks"] == 32 and p["lead_chunks"] == 8
+    assert plan(131072, 65536)[0]["chunk"] == 4096 and plan(1 << 20, 1 << 20)[0]["chunks"] == 4
 
 
 def test_bad_arguments_are_refused(plan):
