@@ -609,7 +609,7 @@ struct bf_plan {
 
 static int bf_check_knobs(const int* k) {
     SLAM_REQUIRE(k[0] == 0 || k[0] == 1 || k[0] == 2 || k[0] == 4 || k[0] == 8, "R must be 0, 1, 2, 4 or 8");
-    SLAM_REQUIRE(k[1] >= 0 && k[1] <= 64, "blocks_per_cu out of range");
+    SLAM_REQUIRE(k[1] >= 0 && k[1] <= 4096, "blocks_per_cu out of range");
     SLAM_REQUIRE(k[2] >= -1 && k[2] <= (1 << 22), "lead_rows out of range");
     SLAM_REQUIRE(k[3] >= 0 && k[3] <= (1 << 22) && k[3] % 32 == 0, "lead_chunk must be a multiple of 32 rows");
     SLAM_REQUIRE(k[4] >= -1 && k[4] <= 4096, "tail out of range");
@@ -655,6 +655,11 @@ static void plan_uniform(int num_cu, const int* knob, int64_t N, int64_t M, int 
     if (S < 1) S = 1;
     int64_t chunk = (M + S - 1) / S;
     chunk = (chunk + SLAM_TILE_ROWS - 1) / SLAM_TILE_ROWS * SLAM_TILE_ROWS;
+    // No chunk longer than 131072 rows: with thousands of query blocks the formula above gives two to four chunks of half a
+    // million rows, and a grid of a few very long dispatch rounds ends on a round that is mostly empty (2^20 x 2^20, the
+    // loop-closure grid: 524288-row chunks 268.3 ms, 262144 256.1, 131072 253.3, 65536 254.0, 16384 255.9 ms;
+    // profiles/r03_blocks_per_cu_sweep.log).
+    if (!forced && chunk > 131072) chunk = 131072;
     if (!forced && M < 16384) {
         // Train sets below the leader regime: a small launch costs launch + drain latency on a grid that may not fill the
         // chip.  Since round 3 a chunk that starts before anybody has published a bound folds its first rows in unfiltered

@@ -86,7 +86,7 @@ def test_shipped_rules_on_a_256_cu_device(plan):
     # grid); more query blocks than CUs: 32 blocks per CU
     p, _ = plan(8192, 65536)
     assert p["chunk"] == 512 and p["qblocks"] == 32 and p["tail_chunks"] == 32 and p["lead_chunks"] == 8
-    assert plan(131072, 65536)[0]["chunk"] == 4096 and plan(1 << 20, 1 << 20)[0]["chunks"] == 4
+    assert plan(131072, 65536)[0]["chunk"] == 4096 and plan(1 << 20, 1 << 20)[0]["chunk"] == 131072   # no chunk longer than that
 
 
 def test_bad_arguments_are_refused(plan):
