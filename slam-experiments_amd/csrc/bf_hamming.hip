@@ -784,9 +784,15 @@ static bf_plan make_plan_core(int num_cu, const int* k, int64_t N, int64_t M, st
     // profiles/r03_ab_cold_start.log feed=1, 4096 x 4096 18.4 -> 17.3 us, 2000 x 2000 10.7 -> 9.8 us; 8192 x 8192 with
     // 256-row chunks 32.8 -> 35.6 us stays on the LDS form).  Rows that lie in pinned host memory (frame-sized host calls)
     // always take the LDS form: every scalar load would be a PCIe round trip.
-    const bool short_chunks = p.chunk <= SLAM_COLD_ROWS && lead_rows == 0 && !rows_on_host;
-    p.sfeed = p.R == 1 && (k[5] == 1 || (k[5] == 0 && (p.chunk >= 2 * SLAM_TILE_ROWS || short_chunks))) ? 1 : 0;
+    // The unfiltered start: 128 rows, and the WHOLE chunk for train sets below the leader regime whose chunks have at most
+    // 384 rows (6000 x 6000 to 12000 x 12000: all the chunks of a query start together, so by the time a filter could
+    // reject anything the chunk is over - 6000 x 6000 25.3 -> 20.6 us, 8192 x 8192 32.6 -> 28.9 us, 10000 x 10000 47.7 ->
+    // 40.6 us with the chunk unfiltered throughout; 12000 x 12000 and 65536 x 4096 with their 384- / 512-row chunks equal
+    // or better filtered; profiles/r03_small_chunk_sweep.log).
     p.cold = k[6] < 0 ? 0 : (k[6] ? k[6] : SLAM_COLD_ROWS);
+    if (k[6] == 0 && lead_rows == 0 && M < 16384 && p.chunk <= 384 && p.cold < p.chunk) p.cold = (p.chunk + 15) / 16 * 16;
+    const bool short_chunks = p.chunk <= p.cold && lead_rows == 0 && !rows_on_host;
+    p.sfeed = p.R == 1 && (k[5] == 1 || (k[5] == 0 && (p.chunk >= 2 * SLAM_TILE_ROWS || short_chunks))) ? 1 : 0;
     p.uni = p.tail == 0 && p.lead == 0 ? p.chunk : 0;
     // one round and no chunk longer than the unfiltered start: the kernel exchanges no bounds at all (passed as -cold)
     if (qb_launch * (int64_t)p.S <= slots && p.chunk <= p.cold && p.lead == 0) p.cold = -p.cold;   // (S: the tail's extra chunks counted)

@@ -103,13 +103,13 @@ def test_plan_tables_and_degenerate_inputs(gpu_ctx):
     assert ctx.plan_info(65536, 65536)["sgpr_feed"] == 1 and ctx.plan_info(1 << 20, 1 << 20)["sgpr_feed"] == 1
     assert ctx.plan_info(65536, 4096)["sgpr_feed"] == 1 and ctx.plan_info(8192, 65536)["sgpr_feed"] == 1
     assert ctx.plan_info(4096, 4096)["sgpr_feed"] == 1 and ctx.plan_info(200, 200)["sgpr_feed"] == 1
-    assert ctx.plan_info(8192, 8192)["sgpr_feed"] == 0 and ctx.plan_info(12000, 12000)["sgpr_feed"] == 0
+    assert ctx.plan_info(8192, 8192)["sgpr_feed"] == 1 and ctx.plan_info(16000, 16000)["sgpr_feed"] == 1
     # small train sets: one block per CU up to 128 rows a chunk, about 8 sqrt(that) beyond; no tail up to two blocks per CU
     cus = ctx.plan_info(200, 200)["cus"]
     if cus == 256:
         for (n_, m_), chunk in (((200, 200), 32), ((2000, 2000), 64), ((4096, 4096), 128), ((8192, 8192), 256), ((65536, 4096), 512)):
             p = ctx.plan_info(n_, m_)
-            assert p["chunk"] == chunk and p["cold_rows"] == 128 and p["lead_rows"] == 0, (n_, m_, p)
+            assert p["chunk"] == chunk and p["cold_rows"] == (max(128, chunk) if chunk <= 384 else 128) and p["lead_rows"] == 0, (n_, m_, p)
         assert ctx.plan_info(4096, 4096)["tail_chunks"] == 0 and ctx.plan_info(12000, 12000)["tail_chunks"] > 0
     n, m = 700, 20000
     rng = np.random.default_rng(3)

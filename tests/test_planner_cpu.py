@@ -2,7 +2,7 @@
 chunk boundary table covers the train rows exactly under every knob setting, and the shipped rules are the measured ones
 (leaders from 16384 rows up, one block per CU up to 128 rows a chunk and about 8 sqrt(that) beyond,
 no tail and no table for grids of up to two blocks per CU, no bound exchange when every chunk fits its unfiltered start,
-SGPR feed for long and for short chunks but never for rows in pinned host memory)."""
+SGPR feed for long chunks and for chunks that are unfiltered throughout but never for rows in pinned host memory)."""
 import itertools
 
 import numpy as np
@@ -65,7 +65,8 @@ def test_shipped_rules_on_a_256_cu_device(plan):
     for (n, m), chunk in (((200, 200), 32), ((1000, 1000), 32), ((2000, 2000), 64), ((4096, 4096), 128), ((8192, 8192), 256),
                           ((12000, 12000), 384), ((65536, 4096), 512)):
         p, _ = plan(n, m)
-        assert p["chunk"] == chunk and p["cold_rows"] == 128 and p["lead_rows"] == 0, (n, m, p)
+        # the unfiltered start is 128 rows - and the whole chunk for chunks of up to 384 rows
+        assert p["chunk"] == chunk and p["cold_rows"] == (max(128, chunk) if chunk <= 384 else 128) and p["lead_rows"] == 0, (n, m, p)
     # sixteen 4096 x 4096 searches in one launch plan their chunks for the whole grid
     assert plan(4096, 4096, qb_all=256)[0]["chunk"] == 512
     # up to two blocks per CU: uniform chunks, no table; with every chunk inside the unfiltered start also no bounds
@@ -73,14 +74,17 @@ def test_shipped_rules_on_a_256_cu_device(plan):
         p, _ = plan(n, m)
         assert p["table_free"] and p["bound_free"] and p["tail_chunks"] == 0, (n, m, p)
     p, _ = plan(12000, 12000)
-    assert not p["table_free"] and not p["bound_free"] and p["tail_chunks"] > 0
+    assert not p["table_free"] and p["bound_free"] and p["tail_chunks"] > 0 and p["cold_rows"] == 384
+    p, _ = plan(16000, 16000)
+    assert not p["table_free"] and not p["bound_free"] and p["cold_rows"] == 128
     p, _ = plan(65536, 65536)
     assert not p["table_free"] and not p["bound_free"] and p["chunk"] == 4096 and p["lead_chunks"] == 1 and p["chunks"] == 19   # 16 blocks per CU
     # the feed: SGPRs for chunks of >= 512 rows and for chunks inside the unfiltered start, the LDS tile in between -
     # and always for rows that lie in pinned host memory unless the chunks are long (those rows were copied to the device)
     assert plan(65536, 65536)[0]["sgpr_feed"] == 1 and plan(8192, 65536)[0]["sgpr_feed"] == 1
     assert plan(4096, 4096)[0]["sgpr_feed"] == 1 and plan(200, 200)[0]["sgpr_feed"] == 1
-    assert plan(8192, 8192)[0]["sgpr_feed"] == 0 and plan(12000, 12000)[0]["sgpr_feed"] == 0
+    assert plan(8192, 8192)[0]["sgpr_feed"] == 1 and plan(12000, 12000)[0]["sgpr_feed"] == 1
+    assert plan(5000, 20000, chunk=256, lead_rows=-1)[0]["sgpr_feed"] == 0           # a filtered one-tile chunk: the LDS tile
     assert plan(4096, 4096, rows_on_host=True)[0]["sgpr_feed"] == 0 and plan(200, 200, rows_on_host=True)[0]["sgpr_feed"] == 0
     # no more query blocks than CUs: 16 blocks per CU and up to 32 shrinking chunks at the end (the 1/8 shard of the headline
     # grid); more query blocks than CUs: 32 blocks per CU
