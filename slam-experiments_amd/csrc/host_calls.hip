@@ -111,10 +111,13 @@ extern "C" int slam_bf_match_host(slam_ctx* ctx, const uint8_t* h_query, int64_t
     if (mode == 3) {
         // cv2.BFMatcher(crossCheck=True).match: the forward and the reverse search (train rows as queries) stay on
         // the device, only the per-query (idx, dist) pair of the mutual nearest neighbours comes back
-        int32_t* fwd_idx = (int32_t*)(db + off_i);
-        int32_t* fwd_dist = (int32_t*)(db + off_d);
-        int32_t* rev_idx = (int32_t*)(db + off_r);
-        int32_t* rev_dist = (int32_t*)(db + off_r + (uint64_t)M * 8);
+        // Frame-sized (zero-copy) calls write both searches' tables straight into the pinned block and the HOST does the
+        // mutual-nearest test (one gather of the reverse table through the forward one, <= 4096 rows: less than the gap in
+        // front of another kernel): ONE launch per call.  Larger calls keep the tables on the device and run cross_emit_kernel.
+        int32_t* fwd_idx = (int32_t*)(io + off_i);
+        int32_t* fwd_dist = (int32_t*)(io + off_d);
+        int32_t* rev_idx = (int32_t*)(io + off_r);
+        int32_t* rev_dist = (int32_t*)(io + off_r + (uint64_t)M * 8);
         int32_t* o_idx = (int32_t*)(io + off_o);
         int32_t* o_dist = (int32_t*)(io + off_o + (uint64_t)N * 4);
         if (N <= SLAM_MAX_TRAIN_PER_PASS && M <= SLAM_MAX_TRAIN_PER_PASS) {
@@ -127,18 +130,31 @@ extern "C" int slam_bf_match_host(slam_ctx* ctx, const uint8_t* h_query, int64_t
             if (int rc = slam_bf_knn2_keep(ctx, dq, N, dt, M, 0, fwd_idx, fwd_dist, keep_in_kernel)) return rc;
             if (int rc = slam_bf_knn2_u256(ctx, dt, M, dq, N, 0, rev_idx, rev_dist)) return rc;
         }
-        if (int rc = slam_cross_launch(ctx, fwd_idx, fwd_dist, N, rev_idx, M, o_idx, o_dist)) return rc;
-        if (!zc) SLAM_HIP(hipMemcpyAsync(hb + off_o, db + off_o, (uint64_t)N * 8, hipMemcpyDeviceToHost, ctx->stream));
-        SLAM_HIP(hipStreamSynchronize(ctx->stream));
-        const int32_t* ri = (const int32_t*)(hb + off_o);
-        const int32_t* rd = (const int32_t*)(hb + off_o + (uint64_t)N * 4);
         int64_t c = 0;
-        for (int64_t n = 0; n < N; n++) {
-            if (ri[n] < 0) continue;
-            h_query_idx[c] = (int32_t)n;
-            h_train_idx[c] = ri[n];
-            h_distance[c] = (float)rd[n];
-            c++;
+        if (zc) {
+            ctx->io_d2h_bytes += (uint64_t)N * 8 + (uint64_t)M * 16;     // the four tables instead of the emitted pair
+            SLAM_HIP(hipStreamSynchronize(ctx->stream));
+            for (int64_t n = 0; n < N; n++) {
+                const int32_t t = fwd_idx[2 * n];
+                if (t < 0 || t >= M || rev_idx[2 * (int64_t)t] != (int32_t)n) continue;
+                h_query_idx[c] = (int32_t)n;
+                h_train_idx[c] = t;
+                h_distance[c] = (float)fwd_dist[2 * n];
+                c++;
+            }
+        } else {
+            if (int rc = slam_cross_launch(ctx, fwd_idx, fwd_dist, N, rev_idx, M, o_idx, o_dist)) return rc;
+            SLAM_HIP(hipMemcpyAsync(hb + off_o, db + off_o, (uint64_t)N * 8, hipMemcpyDeviceToHost, ctx->stream));
+            SLAM_HIP(hipStreamSynchronize(ctx->stream));
+            const int32_t* ri = (const int32_t*)(hb + off_o);
+            const int32_t* rd = (const int32_t*)(hb + off_o + (uint64_t)N * 4);
+            for (int64_t n = 0; n < N; n++) {
+                if (ri[n] < 0) continue;
+                h_query_idx[c] = (int32_t)n;
+                h_train_idx[c] = ri[n];
+                h_distance[c] = (float)rd[n];
+                c++;
+            }
         }
         *h_count = c;
         return SLAM_OK;
