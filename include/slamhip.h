@@ -138,18 +138,22 @@ SLAM_API int slam_bf_knn2_u256_host(slam_ctx* ctx, const uint8_t* h_query, int64
 /* Tuning overrides for experiments, per context.  h_knobs is an int32 array of up to SLAM_BF_KNOBS entries (missing
  * entries and a NULL array mean 0 = the shipped choice):
  *   [0] R             queries per lane: 1, 2, 4 or 8 (shipped: 1)
- *   [1] blocks_per_cu grid size target (shipped: 32, or 64 for query sets with fewer query blocks than CUs)
+ *   [1] blocks_per_cu grid size target (shipped: 16 while there are no more query blocks than CUs, 32 above; train sets
+ *                     below 16384 rows follow the chunk rule of [7] instead)
  *   [2] lead_rows     train rows given to the leader chunks: short chunks at the head of the dispatch order that
  *                     publish exact per-query bounds early (shipped: M/8 up to 8192 for M >= 16384, none below);
  *                     -1 = no leaders
  *   [3] lead_chunk    rows per leader chunk, a multiple of 32 (shipped: about one leader block per CU)
- *   [4] tail          number of linearly shrinking chunks at the end of the grid (shipped: 16); -1 = none
+ *   [4] tail          number of linearly shrinking chunks at the end of the grid (shipped: up to 32, none for grids of
+ *                     at most two blocks per CU); -1 = none
  *   [5] feed          how train rows reach the lanes at R = 1: 1 = through SGPRs (scalar loads, no LDS), -1 = through an LDS
- *                     tile (shipped: SGPRs when a chunk has at least 512 rows, the LDS tile below that)
+ *                     tile (shipped: SGPRs when a chunk has at least 512 rows or is scanned unfiltered throughout and
+ *                     its rows are in device memory, the LDS tile otherwise)
  *   [6] cold          rows a chunk folds in WITHOUT a filter when it starts before anybody has published a bound for its
- *                     queries, a multiple of 16 (shipped: see make_plan in bf_hamming.hip); -1 = none
- *   [7] chunk         rows per uniform chunk for train sets below 16384 rows, a multiple of 32 (shipped: about one block
- *                     per CU, 32 to 512 rows) */
+ *                     queries, a multiple of 16 (shipped: 128, and the whole chunk for train sets below 16384 rows whose
+ *                     chunks have at most 384 rows); -1 = none
+ *   [7] chunk         rows per uniform chunk for train sets below 16384 rows, a multiple of 32 (shipped: one block per CU
+ *                     up to 128 rows a chunk, about 8 sqrt(that) beyond, at most 512) */
 #define SLAM_BF_KNOBS 8
 SLAM_API int slam_bf_set_tuning(slam_ctx* ctx, const int32_t* h_knobs, int count);
 /* The launch plan slam_bf_knn2_u256 would use for N x M on this context: h_plan int32 [10] =
