@@ -361,28 +361,71 @@ def main() -> int:
     rccl_version = ctypes.c_int(0)
     if ctx.lib.slam_comm_version(ctypes.byref(rccl_version)) != 0:
         rccl_version = None
+    # A multi-rank RCCL communicator has never run on the boxes this was developed on (one GPU each; RCCL refuses ranks that
+    # share a device), so its set-up and its first collective round run under a deadline: a bootstrap that waits for a rank
+    # that will not come, or a collective on a fabric that does not answer, becomes a labelled fall-back to the next tier
+    # instead of a run that hangs until somebody kills it.  After a deadline the native call is still running in its helper
+    # thread: the communicator and the context whose stream holds the collective are abandoned (nothing is destroyed), the
+    # rest of the run uses a fresh context, and the process leaves with os._exit once the line is out.
+    deadline = float(os.environ.get("SLAM_BENCH_DEADLINE", "90"))
+    fake_hang = os.environ.get("SLAM_BENCH_FAKE_HANG", "")     # test hook: "init" / "step" - rank 1 never returns from that call
+    abandoned = False
+    sm = None
+    device_index = 0 if os.environ.get("SLAM_BENCH_SINGLE_DEVICE") == "1" else local_rank
     if world > 1:
         # RCCL is the data path.  If its communicator cannot be created on this node, say so loudly and use the
         # library's own direct all-gather over xGMI peer mappings (HIP IPC); if that cannot be set up either,
         # gather through the host, so that a scaling number - labelled as such - still exists.
+        from slamhip.dist import call_with_deadline
+
         force = os.environ.get("SLAM_BENCH_COLLECTIVE", "")    # test hook: "p2p" / "host" skip the tiers above them
         os.environ.setdefault("NCCL_DEBUG", "WARN")            # a failing communicator says why on stderr
         try:
             if force in ("p2p", "host"):
                 raise RuntimeError(f"skipped: SLAM_BENCH_COLLECTIVE={force}")
-            init_comm(ctx, rank, world, rz.bcast)
+            if fake_hang == "init" and rank == 1:
+                rz.bcast(None)                                 # takes part in the id exchange, then "never returns"
+                call_with_deadline(lambda: time.sleep(1e6), deadline, "ncclCommInitRank (simulated hang)")
+            else:
+                init_comm(ctx, rank, world, rz.bcast, deadline=deadline)
             failed = None
         except Exception as exc:   # noqa: BLE001 - any failure of the native init
             failed = f"rccl: {type(exc).__name__}: {exc}"
             print(f"[bench] rank {rank}: RCCL communicator init failed ({exc}); trying peer copies over HIP IPC", file=sys.stderr)
         verdicts = rz.allgather(failed)                        # every rank reaches this collective on every path
         rccl_ok = not any(verdicts)
+        if rccl_ok:
+            # the communicator exists everywhere: prove it with the first pass (train broadcast, search, all-gather, sync)
+            def first_round():
+                m = ShardedMatcher(ctx, rank, world, query, train, collective="rccl", broadcast_train=loop_closure,
+                                   image_rows=image_rows)
+                if fake_hang == "step" and rank == 1:
+                    time.sleep(1e6)
+                m.step()
+                ctx.sync()
+                return m
+
+            try:
+                sm = call_with_deadline(first_round, deadline, "the first RCCL all-gather")
+                failed = None
+            except Exception as exc:   # noqa: BLE001
+                failed = f"rccl: {type(exc).__name__}: {exc}"
+                print(f"[bench] rank {rank}: the first RCCL round failed ({exc}); trying peer copies over HIP IPC", file=sys.stderr)
+            verdicts = rz.allgather(failed)
+            rccl_ok = not any(verdicts)
         if not rccl_ok:
             fallback_reason = "; ".join(f"rank {r}: {v}" for r, v in enumerate(verdicts) if v)
-            ctx.lib.slam_comm_destroy(ctx.handle)
+            abandoned = any(v and "did not return within" in v for v in verdicts)
+            sm = None
+            if abandoned:
+                # somebody is still inside a native call: nothing RCCL touched is reused or destroyed (the old context is
+                # simply left alone: it has no finaliser, and the process leaves through os._exit)
+                ctx = slamhip.Context(device_index)
+            else:
+                ctx.lib.slam_comm_destroy(ctx.handle)
 
-    sm = ShardedMatcher(ctx, rank, world, query, train, collective="rccl" if rccl_ok else None,
-                        broadcast_train=loop_closure, image_rows=image_rows)
+    if sm is None:
+        sm = ShardedMatcher(ctx, rank, world, query, train, collective=None, broadcast_train=False, image_rows=image_rows)
     host_gather = False
     if world > 1 and rccl_ok:
         collective = "rccl"
@@ -485,10 +528,14 @@ def main() -> int:
     if check_rc:
         raise SystemExit("slam_comm_destroy failed")
     if rank == 0:
-        print(json.dumps(out))
-        if not ok:
-            return 1
-    return 0
+        print(json.dumps(out), flush=True)
+    rc = 0 if ok or rank != 0 else 1
+    if abandoned:
+        # a helper thread is still inside a native call that never returned: a normal interpreter exit would wait for
+        # the runtime's teardown behind it
+        sys.stderr.flush()
+        os._exit(rc)
+    return rc
 
 
 if __name__ == "__main__":

@@ -46,13 +46,49 @@ class ShardPlan:
         return self.rows_per_rank * self.world
 
 
-def init_comm(ctx: Context, rank: int, world: int, bcast: Callable[[Optional[bytes]], bytes]) -> None:
-    """Create the RCCL communicator of ``ctx``; ``bcast`` ships rank 0's unique id to everybody."""
+class DeadlineExceeded(RuntimeError):
+    """A native call did not return in time; the thread that made it is still inside it."""
+
+
+def call_with_deadline(fn: Callable[[], object], seconds: Optional[float], what: str):
+    """``fn()`` - in a helper thread when ``seconds`` is given, so that a native call that never returns (a communicator
+    bootstrap waiting for a rank that will not come, a collective on a fabric that does not answer) becomes a
+    ``DeadlineExceeded`` instead of a hung process.  ctypes drops the GIL inside the call and every entry point of the
+    library selects its device itself, so the calling thread does not matter.  After a ``DeadlineExceeded`` the helper thread
+    is still inside the call: whatever it holds must be abandoned, not reused or destroyed, and the process should leave
+    with ``os._exit`` once it has said what happened."""
+    if seconds is None:
+        return fn()
+    import threading
+
+    box = {}
+
+    def run():
+        try:
+            box["value"] = fn()
+        except BaseException as exc:   # noqa: BLE001 - handed to the caller below
+            box["error"] = exc
+
+    t = threading.Thread(target=run, name=f"deadline:{what}", daemon=True)
+    t.start()
+    t.join(seconds)
+    if t.is_alive():
+        raise DeadlineExceeded(f"{what} did not return within {seconds:.0f} s")
+    if "error" in box:
+        raise box["error"]
+    return box.get("value")
+
+
+def init_comm(ctx: Context, rank: int, world: int, bcast: Callable[[Optional[bytes]], bytes],
+              deadline: Optional[float] = None) -> None:
+    """Create the RCCL communicator of ``ctx``; ``bcast`` ships rank 0's unique id to everybody.  ``deadline``: seconds
+    each of the two native calls may take (``call_with_deadline``); the ``bcast`` between them runs on the calling thread,
+    so the launcher's socket is never used from two threads."""
     ident, failure = b"", None
     if rank == 0:
         try:
             buf = ctypes.create_string_buffer(COMM_ID_BYTES)
-            check(ctx.lib.slam_comm_unique_id(buf))
+            call_with_deadline(lambda: check(ctx.lib.slam_comm_unique_id(buf)), deadline, "ncclGetUniqueId")
             ident = buf.raw
         except Exception as exc:   # noqa: BLE001 - the other ranks are waiting in bcast: tell them instead of hanging them
             failure = exc
@@ -63,7 +99,8 @@ def init_comm(ctx: Context, rank: int, world: int, bcast: Callable[[Optional[byt
         raise RuntimeError("rank 0 could not create an RCCL unique id")
     if not isinstance(ident, (bytes, bytearray)) or len(ident) != COMM_ID_BYTES:
         raise ValueError("bcast must return the 128-byte id produced on rank 0")
-    check(ctx.lib.slam_comm_init(ctx.handle, world, rank, ctypes.create_string_buffer(bytes(ident), COMM_ID_BYTES)))
+    ident_buf = ctypes.create_string_buffer(bytes(ident), COMM_ID_BYTES)
+    call_with_deadline(lambda: check(ctx.lib.slam_comm_init(ctx.handle, world, rank, ident_buf)), deadline, "ncclCommInitRank")
 
 
 class PeerMap:

@@ -3,6 +3,7 @@ import ctypes
 import json
 import os
 import subprocess
+import time
 import sys
 
 import numpy as np
@@ -98,6 +99,23 @@ def test_n_gt_1_line_says_which_collective_ran_and_why(built):
     assert 0 < roof["kernel_ms_per_rank"]["min"] <= roof["kernel_ms_per_rank"]["max"] == roof["kernel_ms"]
     assert 0 < roof["valu_int"]["frac_of_32lane_peak"] <= 1 and 0 < roof["valu_int"]["frac_of_issue_floor"] <= 1
     assert cfg["launch_plan"]["qblocks"] == 128
+
+
+def test_a_communicator_set_up_that_never_returns_becomes_a_labelled_fallback(built):
+    """The RCCL set-up runs under a deadline: rank 1 "never returns" from its ncclCommInitRank (simulated), rank 0's real
+    one waits for it in vain - both give up after SLAM_BENCH_DEADLINE seconds, the line says so, the run finishes on the
+    peer-copy tier with a fresh context and the processes leave (os._exit) although helper threads are still stuck."""
+    env = dict(os.environ, SLAM_BENCH_SINGLE_DEVICE="1", SLAM_BENCH_FAKE_HANG="init", SLAM_BENCH_DEADLINE="6")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SLAM_RDZV", "SLAM_BENCH_COLLECTIVE"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"]
+    t0 = time.monotonic()
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert time.monotonic() - t0 < 300, "the run must not wait for the stuck calls"
+    rec = _bench_line(out)
+    assert rec["n_gpus"] == 2 and rec["parity_spot_check"] is True
+    assert rec["config"]["collective"] in ("xgmi-p2p-copies", "host-fallback"), rec["config"]
+    assert "did not return within" in rec["config"]["collective_fallback_reason"], rec["config"]["collective_fallback_reason"]
 
 
 @pytest.mark.parametrize("ranks,force", [(1, ""), (3, "p2p")])

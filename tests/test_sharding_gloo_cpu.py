@@ -73,3 +73,18 @@ def test_shard_plan_edges():
     shards = [np.full((b - a, 2), r, np.int32) for r, (a, b) in enumerate(ShardPlan(10, 4).rows(r) for r in range(4))]
     full = gather_rows_host(ShardPlan(10, 4), shards)
     assert full.shape == (10, 2) and full[:, 0].tolist() == [0, 0, 0, 1, 1, 1, 2, 2, 2, 3]
+
+
+def test_call_with_deadline_turns_a_call_that_never_returns_into_an_error():
+    """What bench.py wraps the RCCL set-up and its first collective round in."""
+    import time
+
+    from slamhip.dist import DeadlineExceeded, call_with_deadline
+
+    assert call_with_deadline(lambda: 5, None, "x") == 5 and call_with_deadline(lambda: 6, 1.0, "x") == 6
+    with pytest.raises(ZeroDivisionError):
+        call_with_deadline(lambda: 1 / 0, 1.0, "x")
+    t0 = time.monotonic()
+    with pytest.raises(DeadlineExceeded, match="the sleeping call did not return within"):
+        call_with_deadline(lambda: time.sleep(30), 0.3, "the sleeping call")
+    assert time.monotonic() - t0 < 5
