@@ -452,7 +452,10 @@ def main() -> int:
 
     # device spin-up, not part of the measurement (see SPIN_UP_PASSES; a loop-closure pass is 0.3 s of load by itself)
     ctx.prof_enable(True)              # creates the event pool now, so that no idle gap precedes the timed region
-    for _ in range(2 if loop_closure else SPIN_UP_PASSES):
+    # (the COUNT is the same on every rank - a pass contains a collective - and covers ~30 ms of load whatever the shard
+    # size: at eight ranks a pass is 0.15 ms, and 24 of them would end before the clock has settled)
+    spin_up = 2 if loop_closure else max(SPIN_UP_PASSES, int(0.030 / (float(sm.per) * n_train / 3.5e12)) + 1)
+    for _ in range(spin_up):
         step()
     barrier()
     for _ in range(args.warmup):
