@@ -345,6 +345,16 @@ SLAM_API int slam_ba_optimize_f64(slam_ctx* ctx, int64_t K, int64_t L, int64_t O
                                   const int32_t* d_free_poses, int64_t n_free, double fx, double fy, double cx, double cy,
                                   double huber_delta, int iterations, double* d_poses2, double* d_points2, void* d_work,
                                   uint64_t work_bytes, double* d_stats);
+/* slam_ba_optimize_f64 on HOST buffers: poses [K,12] and points [L,3] in, the optimised ones out; the index tables the kernel
+ * wants are built inside (two stable counting sorts), a (pose, point) pair observed twice or an index out of range is
+ * refused (SLAM_ERR_INVALID) before anything is launched.  h_pose_fixed [K]: non-zero = the pose holds the gauge.  One
+ * upload, one launch, one download; staging, device arena and workspace belong to the context.  h_stats as d_stats above.
+ * Serialises with the other host-buffer calls of the context. */
+SLAM_API int slam_ba_optimize_host_f64(slam_ctx* ctx, int64_t K, int64_t L, int64_t O, const double* h_poses,
+                                       const double* h_points, const int32_t* h_obs_pose, const int32_t* h_obs_point,
+                                       const double* h_meas, const uint8_t* h_pose_fixed, double fx, double fy, double cx,
+                                       double cy, double huber_delta, int iterations, double* h_poses_out,
+                                       double* h_points_out, double* h_stats);
 
 /* ---- multi-GPU: RCCL all-gather of per-shard result rows ---------------- */
 #define SLAM_COMM_ID_BYTES 128

@@ -87,6 +87,9 @@ SIGNATURES = {
     "slam_ba_backsub_f64": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p]),
     "slam_ba_optimize_workspace": (c_int, [c_int64, c_int64, c_int64, POINTER(c_uint64)]),
+    "slam_ba_optimize_host_f64": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_void_p, c_double, c_double, c_double, c_double, c_double, c_int, c_void_p, c_void_p,
+                                          c_void_p]),
     "slam_ba_optimize_f64": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_void_p, c_int64, c_double, c_double, c_double, c_double, c_double, c_int, c_void_p,
                                      c_void_p, c_void_p, c_uint64, c_void_p]),

@@ -15,7 +15,7 @@ from typing import Optional, Sequence
 
 import numpy as np
 
-from ._lib import check
+from ._lib import SlamHipError, check
 from .device import Context, default_context
 from .pose_opt import se3_exp
 from .reproj import ReprojProblem, poses_to_rt12
@@ -256,14 +256,11 @@ def bundle_adjust_one_launch(poses, points, obs_pose_idx, obs_point_idx, meas, i
     the window goes up once, the dense reduced system is solved on the device, the trials, their costs and the accept /
     reject decisions never leave it, the result comes back once.  For windows of at most 16 moving poses (the reference
     keeps 7 keyframes, ``backend.py:11``)."""
-    import ctypes
-
     ctx = ctx or default_context()
     P = np.asarray(poses, np.float64)
-    T = np.tile(np.eye(4), (P.shape[0], 1, 1))
-    T[:, :3, :4] = (P.reshape(-1, 12) if P.ndim == 2 else poses_to_rt12(P)).reshape(-1, 3, 4)
-    X = np.array(points, np.float64).reshape(-1, 3)
-    K, L = T.shape[0], X.shape[0]
+    T12 = np.ascontiguousarray((P.reshape(-1, 12) if P.ndim == 2 else poses_to_rt12(P)).reshape(-1, 12))
+    X = np.ascontiguousarray(points, np.float64).reshape(-1, 3)
+    K, L = T12.shape[0], X.shape[0]
     op = np.ascontiguousarray(obs_pose_idx, np.int32).reshape(-1)
     ol = np.ascontiguousarray(obs_point_idx, np.int32).reshape(-1)
     meas = np.ascontiguousarray(meas, np.float64).reshape(-1, 2)
@@ -272,46 +269,21 @@ def bundle_adjust_one_launch(poses, points, obs_pose_idx, obs_point_idx, meas, i
         raise ValueError("obs_pose, obs_point and meas must have one row per observation")
     if K < 1 or L < 1:
         raise ValueError("need at least one pose and one point")
-    if O and (op.min() < 0 or op.max() >= K or ol.min() < 0 or ol.max() >= L):
-        raise ValueError("observation index out of range")
-    if O and np.unique(op.astype(np.int64) * L + ol).size != O:
-        raise ValueError("a (pose, point) pair is observed more than once")
-    free = np.ones(K, bool)
-    free[list(fixed_poses)] = False
-    fidx = np.flatnonzero(free).astype(np.int32)
-    pt_obs = np.argsort(ol, kind="stable").astype(np.int32)
-    ps_obs = np.argsort(op, kind="stable").astype(np.int32)
-    pt_ptr = np.zeros(L + 1, np.int32); pt_ptr[1:] = np.cumsum(np.bincount(ol, minlength=L))
-    ps_ptr = np.zeros(K + 1, np.int32); ps_ptr[1:] = np.cumsum(np.bincount(op, minlength=K))
-    # one upload: every table and the state packed into one block (offsets in bytes, 16-byte aligned)
-    parts = [op, ol, meas if O else np.zeros((1, 2)), pt_ptr, pt_obs, ps_ptr, ps_obs, fidx,
-             np.concatenate([T[:, :3, :4].reshape(-1), np.zeros(K * 12)]), np.concatenate([X.reshape(-1), np.zeros(L * 3)])]
-    offs, blob = [], bytearray()
-    for a in parts:
-        raw = np.ascontiguousarray(a).tobytes() or bytes(16)       # an empty table still gets an address
-        offs.append(len(blob))
-        blob += raw + bytes((-len(raw)) % 16)
-    need = ctypes.c_uint64(0)
-    check(ctx.lib.slam_ba_optimize_workspace(K, L, O, ctypes.byref(need)))
+    fixed = np.zeros(K, np.uint8)
+    fixed[list(fixed_poses)] = 1
     fx, fy, cx, cy = (float(v) for v in intrinsics)
-    d_in = ctx.upload(np.frombuffer(bytes(blob), np.uint8))
-    d_work, d_stats = ctx.malloc(need.value), ctx.malloc(64)
+    Tout, Xout, st = np.empty((K, 12)), np.empty((L, 3)), np.empty(8)
+    # ranges, the one-observation-per-(pose, point) rule and the index tables are the library's business (slam_ba_optimize_host_f64)
     try:
-        ptr = lambda i: d_in.ptr + offs[i]
-        check(ctx.lib.slam_ba_optimize_f64(ctx.handle, K, L, O, ptr(0), ptr(1), ptr(2), ptr(3), ptr(4), ptr(5), ptr(6), ptr(7),
-                                           len(fidx), fx, fy, cx, cy, float(huber_delta), int(iterations), ptr(8), ptr(9),
-                                           d_work.ptr, need.value, d_stats.ptr))
-        st = d_stats.download(np.float64, (8,))
-        if not np.isfinite(st[:7]).all() or st[5] != 0:
-            raise RuntimeError("slam_ba_optimize_f64 did not complete (its grid barrier was abandoned); stats = %r" % (st.tolist(),))
-        half = int(st[6])
-        Tout = d_in.view(offs[8] + half * K * 96, K * 96).download(np.float64, (K, 3, 4))
-        Xout = d_in.view(offs[9] + half * L * 24, L * 24).download(np.float64, (L, 3))
-    finally:
-        for b in (d_in, d_work, d_stats):
-            b.free()
+        check(ctx.lib.slam_ba_optimize_host_f64(ctx.handle, K, L, O, T12.ctypes.data, X.ctypes.data, op.ctypes.data, ol.ctypes.data,
+                                                meas.ctypes.data, fixed.ctypes.data, fx, fy, cx, cy, float(huber_delta), int(iterations),
+                                                Tout.ctypes.data, Xout.ctypes.data, st.ctypes.data))
+    except SlamHipError as exc:
+        if exc.code == -1:                       # SLAM_ERR_INVALID: a bad argument, e.g. an index out of range or a pair observed twice
+            raise ValueError(str(exc)) from None
+        raise
     Tr = np.tile(np.eye(4), (K, 1, 1))
-    Tr[:, :3, :4] = Tout
+    Tr[:, :3, :4] = Tout.reshape(K, 3, 4)
     return BAResult(poses=Tr, points=Xout, chi2_initial=float(st[0]), chi2_final=float(st[1]), iterations=int(st[2]))
 
 

@@ -423,6 +423,28 @@ def test_batched_pose_refinement_equals_one_frame_at_a_time_and_the_oracle(gpu_c
     assert be.optimize_poses(np.zeros((0, 4, 4)), [], [], FX, FY, CX, CY) == []
 
 
+def test_one_launch_ba_refuses_bad_windows_before_launching(gpu_ctx):
+    """slam_ba_optimize_host_f64 checks what the kernel would trust: index ranges, one observation per (pose, point), the
+    number of moving poses - a ValueError (SLAM_ERR_INVALID) instead of a launch on a malformed window."""
+    from slamhip.ba import bundle_adjust_one_launch
+
+    poses = np.tile(np.eye(4), (3, 1, 1))
+    pts = np.array([[0.0, 0.0, 5.0], [1.0, 0.5, 6.0]])
+    intr = (FX, FY, CX, CY)
+    ok = bundle_adjust_one_launch(poses, pts, [0, 1, 2, 0], [0, 0, 1, 1], np.full((4, 2), 300.0), intr, iterations=1, ctx=gpu_ctx)
+    assert ok.poses.shape == (3, 4, 4) and np.isfinite(ok.chi2_final)
+    with pytest.raises(ValueError, match="observed twice"):
+        bundle_adjust_one_launch(poses, pts, [0, 1, 1], [0, 1, 1], np.zeros((3, 2)), intr, ctx=gpu_ctx)
+    with pytest.raises(ValueError, match="out of range"):
+        bundle_adjust_one_launch(poses, pts, [0, 3], [0, 1], np.zeros((2, 2)), intr, ctx=gpu_ctx)
+    with pytest.raises(ValueError, match="out of range"):
+        bundle_adjust_one_launch(poses, pts, [0, 1], [0, -1], np.zeros((2, 2)), intr, ctx=gpu_ctx)
+    with pytest.raises(ValueError, match="moving poses"):
+        bundle_adjust_one_launch(np.tile(np.eye(4), (20, 1, 1)), pts, [0, 1], [0, 1], np.zeros((2, 2)), intr, fixed_poses=(0,), ctx=gpu_ctx)
+    with pytest.raises(ValueError):
+        bundle_adjust_one_launch(poses, pts, [0, 1], [0], np.zeros((2, 2)), intr, ctx=gpu_ctx)
+
+
 @pytest.mark.parametrize("K,L,delta,fixed,density", [(7, 300, 0.0, (0, 1), 0.6), (7, 1400, 1.0, (0, 1), 0.6), (3, 40, 1.5, (0,), 0.9),
                                                        (17, 200, 0.0, (0,), 0.5), (5, 60, 0.0, (0, 1, 2, 3, 4), 0.8)])
 def test_one_launch_ba_follows_the_oracle_trajectory(gpu_ctx, K, L, delta, fixed, density):

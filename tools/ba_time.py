@@ -48,7 +48,7 @@ for K, L in ((7, 1400), (16, 5000), (32, 20000)):
     ms = ctx.timer_stop() / 20
     sp.free()
     print(f"K={K} L={L} O={len(op)}: reduce kernels {ms*1e3:.1f} us/call; " +
-          "; ".join(f"{n}: {v[0]*1e3:.1f} ms for {v[1]} accepted steps (chi2 {v[2]:.1f})" for n, v in out.items()), flush=True)
+          "; ".join(f"{n}: {v[0]*1e3:.2f} ms for {v[1]} accepted steps (chi2 {v[2]:.1f})" for n, v in out.items()), flush=True)
 
 # the kernel of the one-launch form alone (device time, everything already resident), at the reference's window
 import ctypes
