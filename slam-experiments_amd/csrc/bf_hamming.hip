@@ -39,10 +39,18 @@
 //     a stale bound is only looser, never wrong.  The leader blocks (lowest
 //     grid.y, dispatched first) publish the exact 2nd-best distance of
 //     everything merged so far when they finish.
-//   * every block folds its top-2 into a per-query 64-bit slot with a CAS loop;
-//     the last block to arrive for a query block (agent-scope ticket) decodes
-//     the slots to (int32 idx, int32 dist) and restores the merge state, so a
-//     call is ONE kernel: no memset, no partial tables, no merge kernel.
+//   * a chunk that starts before anybody has published a bound for its queries
+//     (the first dispatch round of a big search, every block of a small one)
+//     folds its first rows - 128, or the whole chunk of a small train set - into
+//     its top-2 UNFILTERED: no compare, no ballot, no branch per row (a wave
+//     takes the update path when any of its 64 lanes improves, i.e. on about
+//     128 / s of its rows after s rows: early on the filter rejects nothing).
+//   * every block folds its top-2 into a per-query 64-bit slot with two 32-bit
+//     atomic minima (1st key; then the loser or the own 2nd key); the last
+//     block to arrive for a query block (agent-scope ticket, no release fence:
+//     every contribution is a returned memory-side atomic) decodes the slots to
+//     (int32 idx, int32 dist) and restores the merge state, so a call is ONE
+//     kernel: no memset, no partial tables, no merge kernel.
 //   * several independent searches can share one launch (bf_top2_batch_kernel).
 #include "internal.h"
 #include "bf_scan_sgpr.h"
