@@ -13,4 +13,6 @@ cp "$OUT/hbm_counters.json" profiles/hbm_counters.json
 cp "$OUT/hbm_counters.json" "profiles/${ROUND}_hbm_counters.json"
 d=$(find "$OUT/stats_default" -name "*kernel_stats.csv" | head -1); [ -n "$d" ] && cp "$d" "profiles/${ROUND}_bench_default_kernel_stats.csv"
 l=$(find "$OUT/stats_long" -name "*kernel_stats.csv" | head -1); [ -n "$l" ] && cp "$l" "profiles/${ROUND}_bench_kernel_stats.csv"
+c=$(find "$OUT/stats_4096" -name "*kernel_stats.csv" | head -1); [ -n "$c" ] && cp "$c" "profiles/${ROUND}_search_4096x4096_kernel_stats.csv"
+h=$(find "$OUT/stats_shard" -name "*kernel_stats.csv" | head -1); [ -n "$h" ] && cp "$h" "profiles/${ROUND}_search_8192x65536_kernel_stats.csv"
 ls -la profiles | grep "${ROUND}_\|hbm_counters.json"

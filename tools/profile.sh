@@ -28,6 +28,9 @@ SLAM_BENCH_SINGLE_DEVICE=1 SLAM_BENCH_COLLECTIVE=p2p $PY bench.py --gpus 2 --wor
 SLAM_BENCH_SINGLE_DEVICE=1 SLAM_BENCH_COLLECTIVE=p2p $PY bench.py --gpus 2 --steps 10 --warmup 2 > $OUT/bench_2ranks_one_gpu.json 2> $OUT/bench_2ranks_one_gpu.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_default -o stats -- $PY bench.py > $OUT/bench_default_under_rocprof.json 2> $OUT/stats_default.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_long -o stats -- $PY bench.py --steps 400 --warmup 20 --no-reproj --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/stats_long.err
+# BASELINE configs[1] (4096 x 4096) and the 1/8 shard of the headline grid under the same profiler
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_4096 -o stats -- $PY tools/run_search.py 4096x4096 400 > /dev/null 2> $OUT/stats_4096.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_shard -o stats -- $PY tools/run_search.py 8192x65536 200 > /dev/null 2> $OUT/stats_shard.err
 echo "kernel stats done"
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --output-format csv -d $OUT/sq1 -o sq1 -- $PY $B --no-reproj > /dev/null 2> $OUT/sq1.err
 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY --output-format csv -d $OUT/sq2 -o sq2 -- $PY $B --no-reproj > /dev/null 2> $OUT/sq2.err
