@@ -37,7 +37,8 @@ def test_spin_barrier_orders_ranks_and_a_dead_rank_is_an_error():
     out, _ = _run("spin", 4)
     assert out.returncode == 0 and "RDZV_OK" in out.stdout, (out.stdout, out.stderr[-2000:])
     us = float(out.stdout.split("SPIN_US")[1].split()[0])
-    assert us < 400.0, us                                # the socket barrier is 170-630 us; this one is a few (loaded CI boxes: be generous)
+    assert us < 5000.0, us                               # a few microseconds with a core per rank (the socket barrier: 170-630 us); a box with
+                                                         # fewer cores than ranks deschedules spinners - only a runaway is an error here
     out, dt = _run("spin-die", 3, {"RDZV_TIMEOUT": "4"})
     assert out.returncode != 0 and dt < 60, (out.returncode, dt)
     assert "RDZV_ERROR rank 0" in out.stdout and "[1]" in out.stdout, (out.stdout, out.stderr[-2000:])
