@@ -73,6 +73,8 @@ def _load():
     lib.oracle_pose_normal_eq_f64.restype = i32
     lib.oracle_pose_lm_f64.argtypes = [vp, vp, vp, i64, dbl, dbl, dbl, dbl, i32, i32, dbl, dbl, vp, vp, vp, vp, vp]
     lib.oracle_pose_lm_f64.restype = i32
+    lib.oracle_ba_lm_f64.argtypes = [i64, i64, i64, vp, vp, vp, vp, vp, vp, dbl, dbl, dbl, dbl, dbl, i32, vp, vp, vp]
+    lib.oracle_ba_lm_f64.restype = i32
     _lib = lib
     return lib
 
@@ -531,3 +533,27 @@ def ba_lm_np(poses12, points, obs_pose, obs_point, meas, fx, fy, cx, cy, iterati
         if not ok:
             break
     return T, X, cost0, cost, accepted, lams
+
+
+def ba_lm_c(poses12, points, obs_pose, obs_point, meas, fx, fy, cx, cy, iterations: int = 10, fixed_poses=(0,),
+            huber_delta: float = 0.0):
+    """The same window bundle adjustment as ``ba_lm_np`` in plain C on one host core (oracle/ba_lm_oracle.c: 3x3 inverses
+    by cofactors, Gaussian elimination with partial pivoting for the reduced system, a scaling-and-squaring series for the
+    exponential): the CPU baseline of that path and a second oracle-side statement that the CPU suite holds against
+    ``ba_lm_np``.  Returns (T [K,4,4], X [L,3], cost0, cost, accepted steps, trials)."""
+    P = np.ascontiguousarray(poses12, np.float64).reshape(-1, 12)
+    X = np.ascontiguousarray(points, np.float64).reshape(-1, 3)
+    K, L = P.shape[0], X.shape[0]
+    op = np.ascontiguousarray(obs_pose, np.int32).reshape(-1)
+    ol = np.ascontiguousarray(obs_point, np.int32).reshape(-1)
+    m = np.ascontiguousarray(meas, np.float64).reshape(-1, 2)
+    fixed = np.zeros(K, np.uint8)
+    fixed[list(fixed_poses)] = 1
+    Pout, Xout, stats = np.empty((K, 12)), np.empty((L, 3)), np.zeros(4)
+    rc = _load().oracle_ba_lm_f64(K, L, op.shape[0], _p(P), _p(X), _p(op), _p(ol), _p(m), _p(fixed), fx, fy, cx, cy,
+                                  float(huber_delta), int(iterations), _p(Pout), _p(Xout), _p(stats))
+    assert rc == 0
+    T = np.tile(np.eye(4), (K, 1, 1))
+    T[:, :3, :4] = Pout.reshape(K, 3, 4)
+    return T, Xout, float(stats[0]), float(stats[1]), int(stats[2]), int(stats[3])
+

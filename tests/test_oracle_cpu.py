@@ -216,3 +216,49 @@ def test_pose_lm_c_and_numpy_statements_agree():
     # no edges: the pose comes back unchanged, no inliers
     Tc, inl_c, _, acc = oracle.pose_lm_c(np.eye(4)[:3, :4], np.zeros((0, 3)), np.zeros((0, 2)), FX, FY, CX, CY)
     assert np.array_equal(Tc.reshape(3, 4), np.eye(4)[:3, :4]) and inl_c.size == 0 and acc == 0
+
+
+def _ba_window(rng, K, L, density, noise=0.5):
+    from scipy.spatial.transform import Rotation
+
+    FX, FY, CX, CY = 458.654, 457.296, 367.215, 248.375
+    T = np.tile(np.eye(4), (K, 1, 1))
+    for k in range(K):
+        T[k, :3, :3] = Rotation.from_rotvec(rng.uniform(-0.1, 0.1, 3)).as_matrix()
+        T[k, :3, 3] = rng.uniform(-0.6, 0.6, 3)
+    X = np.c_[rng.uniform(-4, 4, (L, 2)), rng.uniform(6, 15, L)]
+    vis = rng.uniform(size=(K, L)) < density
+    vis[0, :] = True
+    op, ol = np.nonzero(vis)
+    pc = np.einsum("oij,oj->oi", T[op, :3, :3], X[ol]) + T[op, :3, 3]
+    meas = np.c_[FX * pc[:, 0] / pc[:, 2] + CX, FY * pc[:, 1] / pc[:, 2] + CY] + rng.normal(0, noise, (len(op), 2))
+    meas = meas.astype(np.int32).astype(np.float64)
+    T0 = np.stack([oracle.se3_exp_np(rng.normal(0, 0.01, 6)) @ T[k] for k in range(K)])
+    X0 = X + rng.normal(0, 0.05, X.shape)
+    return T0, X0, op.astype(np.int32), ol.astype(np.int32), meas, (FX, FY, CX, CY)
+
+
+def test_ba_lm_c_and_numpy_statements_agree():
+    """oracle/ba_lm_oracle.c (cofactor inverses, Gaussian elimination, series exponential; the CPU baseline of the window
+    bundle adjustment) and oracle.ba_lm_np (numpy inverses and solver, scipy expm) state the same Schur-complement LM
+    independently: the same number of accepted steps, costs to 1e-9 relative, poses to 1e-8, points to 1e-7 - with and
+    without the Huber kernel, with several fixed poses, with a point nobody observes and with nothing free to move."""
+    for seed, K, L, delta, fixed, iters in ((1, 4, 60, 0.0, (0,), 6), (2, 7, 120, 1.0, (0, 1), 5), (3, 3, 25, 2.0, (0,), 10),
+                                            (4, 5, 40, 0.0, (0, 1, 2, 3, 4), 4)):
+        rng = np.random.default_rng(seed)
+        T0, X0, op, ol, meas, (fx, fy, cx, cy) = _ba_window(rng, K, L, 0.6)
+        if seed == 3:                                   # a point nobody observes stays where it is
+            keep = ol != 7
+            op, ol, meas = op[keep], ol[keep], meas[keep]
+        P0 = np.ascontiguousarray(T0[:, :3, :4]).reshape(K, 12)
+        Tn, Xn, c0n, cn, accn, _ = oracle.ba_lm_np(P0, X0, op, ol, meas, fx, fy, cx, cy, iters, fixed, delta)
+        Tc, Xc, c0c, cc, accc, trials = oracle.ba_lm_c(P0, X0, op, ol, meas, fx, fy, cx, cy, iters, fixed, delta)
+        assert accc == accn and trials >= accc, (seed, accc, accn)
+        assert abs(c0c - c0n) <= 1e-9 * max(1.0, c0n) and abs(cc - cn) <= 1e-9 * max(1.0, cn), (seed, c0c, c0n, cc, cn)
+        assert np.abs(Tc - Tn).max() <= 1e-8 and np.abs(Xc - Xn).max() <= 1e-7, (seed, np.abs(Tc - Tn).max(), np.abs(Xc - Xn).max())
+        if len(fixed) < K:
+            assert cc < c0c                             # it did optimise
+        else:
+            assert accc == 0 and np.array_equal(Tc, T0) and np.array_equal(Xc, X0)
+        if seed == 3:
+            assert np.array_equal(Xc[7], X0[7])

@@ -9,6 +9,8 @@ from slamhip.device import default_context
 from slamhip.ba import bundle_adjust, bundle_adjust_device, bundle_adjust_one_launch, SchurProblem
 from slamhip.pose_opt import se3_exp
 from scipy.spatial.transform import Rotation
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from oracle import oracle
 
 FX, FY, CX, CY = 458.654, 457.296, 367.215, 248.375
 ctx = default_context()
@@ -35,6 +37,13 @@ for K, L in ((7, 1400), (16, 5000), (32, 20000)):
         t = time.perf_counter()
         r = fn(T0, X0, op, ol, meas, (FX, FY, CX, CY), iterations=5, fixed_poses=(0, 1), ctx=ctx)
         out[name] = (time.perf_counter() - t, r.iterations, r.chi2_final)
+    # the same five steps in plain C on ONE host core (oracle/ba_lm_oracle.c: test infrastructure, the CPU baseline of this path)
+    if L <= 5000:
+        p0 = np.ascontiguousarray(T0[:, :3, :4]).reshape(K, 12)
+        oracle.ba_lm_c(p0, X0, op, ol, meas, FX, FY, CX, CY, 1, (0, 1), 0.0)
+        t = time.perf_counter()
+        rc = oracle.ba_lm_c(p0, X0, op, ol, meas, FX, FY, CX, CY, 5, (0, 1), 0.0)
+        out["plain C on one host core"] = (time.perf_counter() - t, rc[4], rc[3])
     sp = SchurProblem(ctx, K, L, op, ol, meas, (FX, FY, CX, CY))
     p12 = T0[:, :3, :4].reshape(K, 12)
     sp.reduce(p12, X0, 0.0, 1.0)
