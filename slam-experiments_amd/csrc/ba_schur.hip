@@ -33,6 +33,21 @@ struct ba_cam { double fx, fy, cx, cy; };
 //   [36..56] upper triangle of Jp^T w Jp (21)   [57..62] Jp^T w e (6)
 //   [63..68] upper triangle of Jq^T w Jq (6)    [69..71] Jq^T w e (3)    [72] rho(e.e)
 #define BA_REC 73
+// The records are kept observation-major (73 consecutive doubles per observation).  Two field-major layouts - field f
+// of observation o at rec[f * O + o], and the same inside tiles of 64 observations - were measured with
+// tools/ba_phase_probe.py and were SLOWER, although they make a wave's loads contiguous: the pose and pair phases of the
+// one-launch form went from 20 to 48 us at the reference's window.  Behind a grid barrier every read comes from memory
+// and a phase is bound by what ONE compute unit can pull (about 30 GB/s here: ~17 ns per observation and CU in the
+// point, pose and pair phases alike); a thread that walks its own contiguous record keeps more of those reads in flight
+// than 46 separate streams do.  Hence the other remedy: more workgroups per phase (bg_shape).
+struct ba_rec_ref {
+    double* base;
+    __device__ __forceinline__ double& operator[](int f) const { return base[f]; }
+};
+struct ba_recs {
+    double* p;
+    __device__ __forceinline__ ba_rec_ref of(int o) const { return {p + (size_t)o * BA_REC}; }
+};
 
 __device__ __forceinline__ double ba_wave_sum(double v) {
 #pragma unroll
@@ -45,8 +60,7 @@ __device__ __forceinline__ double ba_wave_sum(double v) {
 __device__ __forceinline__ void ba_obs_body(const double* __restrict__ poses, const double* __restrict__ points,
                                             const int* __restrict__ obs_pose, const int* __restrict__ obs_point,
                                             const double2* __restrict__ meas, int O, ba_cam cam, double delta, int K, int L,
-                                            unsigned int* __restrict__ index_errors, double* __restrict__ rec, int block) {
-    const int o = block * BA_THREADS + threadIdx.x;
+                                            unsigned int* __restrict__ index_errors, const ba_recs rec, const int o) {
     if (o >= O) return;
     int k = obs_pose[o], l = obs_point[o];
     bool bad = false;
@@ -81,7 +95,7 @@ __device__ __forceinline__ void ba_obs_body(const double* __restrict__ poses, co
         const double en = sqrt(c2);
         if (en > delta) { w = delta / en; rho = 2.0 * delta * en - delta * delta; }
     }
-    double* r = rec + (size_t)o * BA_REC;
+    const ba_rec_ref r = rec.of(o);
 #pragma unroll
     for (int a = 0; a < 6; a++)
 #pragma unroll
@@ -111,19 +125,18 @@ __global__ __launch_bounds__(BA_THREADS) void ba_obs_kernel(const double* __rest
                                                             double delta, int K, int L,
                                                             unsigned int* __restrict__ index_errors,
                                                             double* __restrict__ rec) {
-    ba_obs_body(poses, points, obs_pose, obs_point, meas, O, cam, delta, K, L, index_errors, rec, (int)blockIdx.x);
+    ba_obs_body(poses, points, obs_pose, obs_point, meas, O, cam, delta, K, L, index_errors, ba_recs{rec}, (int)(blockIdx.x * BA_THREADS + threadIdx.x));
 }
 
 // per point: Hll, bl over its observations (CSR row, ascending), E = (Hll + lam I)^-1, Y_o = Hpl_o E
 __device__ __forceinline__ void ba_point_body(const int* __restrict__ pt_ptr, const int* __restrict__ pt_obs, int L, double lam,
-                                              double* __restrict__ rec, double* __restrict__ E, double* __restrict__ bl,
-                                              double* __restrict__ hll_diag /*[L,3] or null*/, int block) {
-    const int l = block * BA_THREADS + threadIdx.x;
+                                              const ba_recs rec, double* __restrict__ E, double* __restrict__ bl,
+                                              double* __restrict__ hll_diag /*[L,3] or null*/, const int l) {
     if (l >= L) return;
     double h[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
     const int a0 = pt_ptr[l], a1 = pt_ptr[l + 1];
     for (int i = a0; i < a1; i++) {
-        const double* r = rec + (size_t)pt_obs[i] * BA_REC;
+        const ba_rec_ref r = rec.of(pt_obs[i]);
 #pragma unroll
         for (int k = 0; k < 6; k++) h[k] += r[63 + k];
 #pragma unroll
@@ -149,7 +162,7 @@ __device__ __forceinline__ void ba_point_body(const int* __restrict__ pt_ptr, co
         hll_diag[(size_t)l * 3 + 2] = h[5];
     }
     for (int i = a0; i < a1; i++) {
-        double* r = rec + (size_t)pt_obs[i] * BA_REC;
+        const ba_rec_ref r = rec.of(pt_obs[i]);
 #pragma unroll
         for (int a = 0; a < 6; a++)
 #pragma unroll
@@ -163,7 +176,7 @@ __global__ __launch_bounds__(BA_THREADS) void ba_point_kernel(const int* __restr
                                                               double* __restrict__ rec, double* __restrict__ E,
                                                               double* __restrict__ bl,
                                                               double* __restrict__ hll_diag /*[L,3] or null*/) {
-    ba_point_body(pt_ptr, pt_obs, L, lam, rec, E, bl, hll_diag, (int)blockIdx.x);
+    ba_point_body(pt_ptr, pt_obs, L, lam, ba_recs{rec}, E, bl, hll_diag, (int)(blockIdx.x * BA_THREADS + threadIdx.x));
 }
 
 // block-wide fixed-order sum of NT per-thread accumulators into out[NT] (shared), all threads return after it
@@ -181,18 +194,20 @@ __device__ __forceinline__ void ba_block_sum(const double (&acc)[NT], double (*s
     __syncthreads();
 }
 
-// one block per pose k: Hpp (21), bp (6), y = sum Y_o bl (6), cost (1) over the pose's observation list
-__device__ __forceinline__ void ba_pose_body(const int* __restrict__ ps_ptr, const int* __restrict__ ps_obs,
-                                             const int* __restrict__ obs_point, const double* __restrict__ rec,
-                                             const double* __restrict__ bl, double* __restrict__ Hpp /*[K,21]*/,
-                                             double* __restrict__ bp /*[K,6]*/, double* __restrict__ ybl /*[K,6]*/,
-                                             double* __restrict__ cost /*[K]*/, double (*sw)[34], double* out, const int k) {
+// one block per pose k, or per slice [begin, end) of its observation list: Hpp (21), bp (6), y = sum Y_o bl (6) and the
+// cost (1) over those entries, stored as block `slot` of the four output arrays (the pose itself when the block takes the
+// whole list; slice s of nsub, slot k * nsub + s, in the one-launch form, whose consumers add the slices in order)
+__device__ __forceinline__ void ba_pose_body(const int* __restrict__ ps_obs, const int* __restrict__ obs_point, const ba_recs rec,
+                                             const double* __restrict__ bl, double* __restrict__ Hpp /*[.,21]*/,
+                                             double* __restrict__ bp /*[.,6]*/, double* __restrict__ ybl /*[.,6]*/,
+                                             double* __restrict__ cost /*[.]*/, double (*sw)[34], double* out, const int begin,
+                                             const int end, const int slot) {
     double acc[34];
 #pragma unroll
     for (int i = 0; i < 34; i++) acc[i] = 0.0;
-    for (int i = ps_ptr[k] + threadIdx.x; i < ps_ptr[k + 1]; i += BA_THREADS) {
+    for (int i = begin + threadIdx.x; i < end; i += BA_THREADS) {
         const int o = ps_obs[i];
-        const double* r = rec + (size_t)o * BA_REC;
+        const ba_rec_ref r = rec.of(o);
         const double* b = bl + (size_t)obs_point[o] * 3;
 #pragma unroll
         for (int t = 0; t < 27; t++) acc[t] += r[36 + t];
@@ -201,18 +216,18 @@ __device__ __forceinline__ void ba_pose_body(const int* __restrict__ ps_ptr, con
         acc[33] += r[72];
     }
     ba_block_sum<34>(acc, sw, out);
-    if (threadIdx.x < 21) Hpp[(size_t)k * 21 + threadIdx.x] = out[threadIdx.x];
+    if (threadIdx.x < 21) Hpp[(size_t)slot * 21 + threadIdx.x] = out[threadIdx.x];
     if (threadIdx.x < 6) {
-        bp[(size_t)k * 6 + threadIdx.x] = out[21 + threadIdx.x];
-        ybl[(size_t)k * 6 + threadIdx.x] = out[27 + threadIdx.x];
+        bp[(size_t)slot * 6 + threadIdx.x] = out[21 + threadIdx.x];
+        ybl[(size_t)slot * 6 + threadIdx.x] = out[27 + threadIdx.x];
     }
-    if (threadIdx.x == 0) cost[k] = out[33];
+    if (threadIdx.x == 0) cost[slot] = out[33];
 }
 
 __global__ __launch_bounds__(BA_THREADS) void ba_pose_kernel(const int* __restrict__ ps_ptr,
                                                              const int* __restrict__ ps_obs,
                                                              const int* __restrict__ obs_point,
-                                                             const double* __restrict__ rec,
+                                                             double* __restrict__ rec,
                                                              const double* __restrict__ bl,
                                                              double* __restrict__ Hpp /*[K,21]*/,
                                                              double* __restrict__ bp /*[K,6]*/,
@@ -220,7 +235,27 @@ __global__ __launch_bounds__(BA_THREADS) void ba_pose_kernel(const int* __restri
                                                              double* __restrict__ cost /*[K]*/) {
     __shared__ double sw[4][34];
     __shared__ double out[34];
-    ba_pose_body(ps_ptr, ps_obs, obs_point, rec, bl, Hpp, bp, ybl, cost, sw, out, (int)blockIdx.x);
+    const int k = (int)blockIdx.x;
+    ba_pose_body(ps_obs, obs_point, ba_recs{rec}, bl, Hpp, bp, ybl, cost, sw, out, ps_ptr[k], ps_ptr[k + 1], k);
+}
+
+// this thread's share of W[k1,k2] over the entries [begin, end) of k1's observation list, the partner observation of k2
+// looked up per point
+__device__ __forceinline__ void ba_pair_accumulate(const int* __restrict__ ps_obs, const int* __restrict__ obs_point,
+                                                   const int* __restrict__ lookup, int L, const ba_recs rec, int k1, int k2,
+                                                   int begin, int end, double (&acc)[36]) {
+    for (int i = begin + threadIdx.x; i < end; i += BA_THREADS) {
+        const int o1 = ps_obs[i];
+        const int o2 = k1 == k2 ? o1 : lookup[(size_t)k2 * L + obs_point[o1]];
+        if (o2 < 0) continue;
+        const ba_rec_ref y = rec.of(o1);   // [18 + ..]: Y of (k1, l)
+        const ba_rec_ref h = rec.of(o2);   // [0 + ..]: Hpl of (k2, l)
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+            for (int b = 0; b < 6; b++)
+                acc[a * 6 + b] += y[18 + a * 3] * h[b * 3] + y[18 + a * 3 + 1] * h[b * 3 + 1] + y[18 + a * 3 + 2] * h[b * 3 + 2];
+    }
 }
 
 // one block per pose pair (k1 <= k2): W[k1,k2] = sum over points seen by both of Y_(k1,l) Hpl_(k2,l)^T (6x6).
@@ -228,7 +263,7 @@ __global__ __launch_bounds__(BA_THREADS) void ba_pose_kernel(const int* __restri
 __device__ __forceinline__ void ba_pair_body(const int* __restrict__ ps_ptr, const int* __restrict__ ps_obs,
                                              const int* __restrict__ obs_point,
                                              const int* __restrict__ lookup /*[K,L] obs of (pose, point) or -1*/, int K, int L,
-                                             const double* __restrict__ rec, double* __restrict__ W /*[K,K,36]*/,
+                                             const ba_recs rec, double* __restrict__ W /*[K,K,36]*/,
                                              double (*sw)[36], double* out, int pair) {
     int k1 = 0;
     while (pair >= K - k1) { pair -= K - k1; k1++; }
@@ -236,18 +271,7 @@ __device__ __forceinline__ void ba_pair_body(const int* __restrict__ ps_ptr, con
     double acc[36];
 #pragma unroll
     for (int i = 0; i < 36; i++) acc[i] = 0.0;
-    for (int i = ps_ptr[k1] + threadIdx.x; i < ps_ptr[k1 + 1]; i += BA_THREADS) {
-        const int o1 = ps_obs[i];
-        const int o2 = lookup[(size_t)k2 * L + obs_point[o1]];
-        if (o2 < 0) continue;
-        const double* y = rec + (size_t)o1 * BA_REC + 18;   // Y of (k1, l)
-        const double* h = rec + (size_t)o2 * BA_REC;        // Hpl of (k2, l)
-#pragma unroll
-        for (int a = 0; a < 6; a++)
-#pragma unroll
-            for (int b = 0; b < 6; b++)
-                acc[a * 6 + b] += y[a * 3] * h[b * 3] + y[a * 3 + 1] * h[b * 3 + 1] + y[a * 3 + 2] * h[b * 3 + 2];
-    }
+    ba_pair_accumulate(ps_obs, obs_point, lookup, L, rec, k1, k2, ps_ptr[k1], ps_ptr[k1 + 1], acc);
     ba_block_sum<36>(acc, sw, out);
     if (threadIdx.x < 36) W[((size_t)k1 * K + k2) * 36 + threadIdx.x] = out[threadIdx.x];
 }
@@ -256,15 +280,15 @@ __global__ __launch_bounds__(BA_THREADS) void ba_pair_kernel(const int* __restri
                                                              const int* __restrict__ ps_obs,
                                                              const int* __restrict__ obs_point,
                                                              const int* __restrict__ lookup, int K, int L,
-                                                             const double* __restrict__ rec, double* __restrict__ W) {
+                                                             double* __restrict__ rec, double* __restrict__ W) {
     __shared__ double sw[4][36];
     __shared__ double out[36];
-    ba_pair_body(ps_ptr, ps_obs, obs_point, lookup, K, L, rec, W, sw, out, (int)blockIdx.x);
+    ba_pair_body(ps_ptr, ps_obs, obs_point, lookup, K, L, ba_recs{rec}, W, sw, out, (int)blockIdx.x);
 }
 
 // per point: dl = E (-bl - sum_{o of l} Hpl_o^T dp_pose(o))
 __device__ __forceinline__ void ba_backsub_body(const int* __restrict__ pt_ptr, const int* __restrict__ pt_obs,
-                                                const int* __restrict__ obs_pose, int L, const double* __restrict__ rec,
+                                                const int* __restrict__ obs_pose, int L, const ba_recs rec,
                                                 const double* __restrict__ E, const double* __restrict__ bl,
                                                 const double* __restrict__ dp /*[K,6]*/, double* __restrict__ dl /*[L,3]*/,
                                                 int block) {
@@ -274,7 +298,7 @@ __device__ __forceinline__ void ba_backsub_body(const int* __restrict__ pt_ptr, 
     const int a0 = pt_ptr[l], a1 = pt_ptr[l + 1];
     for (int i = a0; i < a1; i++) {
         const int o = pt_obs[i];
-        const double* r = rec + (size_t)o * BA_REC;
+        const ba_rec_ref r = rec.of(o);
         const double* d = dp + (size_t)obs_pose[o] * 6;
 #pragma unroll
         for (int c = 0; c < 3; c++)
@@ -290,12 +314,12 @@ __device__ __forceinline__ void ba_backsub_body(const int* __restrict__ pt_ptr, 
 __global__ __launch_bounds__(BA_THREADS) void ba_backsub_kernel(const int* __restrict__ pt_ptr,
                                                                 const int* __restrict__ pt_obs,
                                                                 const int* __restrict__ obs_pose, int L,
-                                                                const double* __restrict__ rec,
+                                                                double* __restrict__ rec,
                                                                 const double* __restrict__ E,
                                                                 const double* __restrict__ bl,
                                                                 const double* __restrict__ dp /*[K,6]*/,
                                                                 double* __restrict__ dl /*[L,3]*/) {
-    ba_backsub_body(pt_ptr, pt_obs, obs_pose, L, rec, E, bl, dp, dl, (int)blockIdx.x);
+    ba_backsub_body(pt_ptr, pt_obs, obs_pose, L, ba_recs{rec}, E, bl, dp, dl, (int)blockIdx.x);
 }
 
 // robust cost only (an LM trial needs nothing else from the candidate state): one block per pose
@@ -394,7 +418,7 @@ extern "C" int slam_ba_backsub_f64(slam_ctx* ctx, int64_t L, const int32_t* d_pt
                  "slam_ba_backsub_f64: null device pointer");
     SLAM_HIP(hipSetDevice(ctx->device));
     ba_backsub_kernel<<<(unsigned)((L + BA_THREADS - 1) / BA_THREADS), BA_THREADS, 0, ctx->stream>>>(
-        d_pt_ptr, d_pt_obs, d_obs_pose, (int)L, d_rec, d_E, d_bl, d_dp, d_dl);
+        d_pt_ptr, d_pt_obs, d_obs_pose, (int)L, (double*)d_rec, d_E, d_bl, d_dp, d_dl);
     SLAM_HIP(hipGetLastError());
     return SLAM_OK;
 }
@@ -418,18 +442,21 @@ extern "C" int slam_ba_backsub_f64(slam_ctx* ctx, int64_t L, const int32_t* d_pt
 // `abort`, which every workgroup checks behind every barrier, so a fault ends the launch instead of hanging the GPU.
 // =====================================================================================================================
 struct bg_ctl {
-    unsigned int arrive, gen;     // the grid barrier
-    int abort, solved;            // launch abandoned; did workgroup 0's factorisation succeed
+    unsigned int arrive; unsigned int pad0[31];   // the grid barrier: the ticket counter and the generation word the waiters poll
+    unsigned int gen; unsigned int pad1[31];      // live in cache lines of their own
+    int abort, solved;                            // launch abandoned; did workgroup 0's factorisation succeed
 };
 
 struct bg_args {
-    int K, L, O, iterations, nfree, nblocks;
+    int K, L, O, iterations, nfree, nblocks, nsub;
     const int* obs_pose; const int* obs_point; const double2* meas;
     const int* pt_ptr; const int* pt_obs; const int* ps_ptr; const int* ps_obs; const int* free_list;
     int* lookup;
     double* T; double* X;                                        // [2][K*12], [2][L*3]
     double* rec; double* E; double* bl; double* hll;             // [O*BA_REC], [L*9], [L*3], [L*3]
-    double* Hpp; double* bp; double* ybl; double* costk; double* costn; double* W;   // [K*21] [K*6] [K*6] [K] [K] [K*K*36]
+    // per pose and slice (slot k * nsub + s): [.*21] [.*6] [.*6] [.]; per pair of free poses and slice: [.*36]; bpc [K*6]:
+    // the slices of bp added up (workgroup 0, with the solve), for the gain ratio's denominator
+    double* Hpp; double* bp; double* ybl; double* costk; double* bpc; double* W;
     double* dp; double* dl; double* part;                        // [K*6], [L*3], [nblocks][2] (gain-ratio denominator, candidate cost)
     bg_ctl* ctl;
     double* stats;
@@ -455,7 +482,7 @@ __device__ __forceinline__ bool bg_grid_sync(bg_ctl* c, unsigned int nblocks, un
         } else {
             unsigned int polls = 0;
             while (__hip_atomic_load(&c->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
-                if (++polls > (1u << 22) || __hip_atomic_load(&c->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                if (++polls > (1u << 22) || ((polls & 63) == 0 && __hip_atomic_load(&c->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
                     __hip_atomic_store(&c->abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     break;
                 }
@@ -469,25 +496,168 @@ __device__ __forceinline__ bool bg_grid_sync(bg_ctl* c, unsigned int nblocks, un
     return bg_load(&c->abort) == 0;
 }
 
-// W block of one pair of poses (k1 <= k2), see ba_pair_body
-__device__ __forceinline__ void bg_pair(const bg_args& a, int k1, int k2, double (*sw)[36], double* out) {
+// slice [begin, end) of k1's list towards the W block of one pair of poses (k1 <= k2), see ba_pair_body; stored as block `slot`
+__device__ __forceinline__ void bg_pair(const bg_args& a, int k1, int k2, int begin, int end, int slot, double (*sw)[36], double* out) {
     double acc[36];
 #pragma unroll
     for (int i = 0; i < 36; i++) acc[i] = 0.0;
-    for (int i = a.ps_ptr[k1] + threadIdx.x; i < a.ps_ptr[k1 + 1]; i += BA_THREADS) {
-        const int o1 = a.ps_obs[i];
-        const int o2 = k1 == k2 ? o1 : a.lookup[(size_t)k2 * a.L + a.obs_point[o1]];
-        if (o2 < 0) continue;
-        const double* y = a.rec + (size_t)o1 * BA_REC + 18;
-        const double* h = a.rec + (size_t)o2 * BA_REC;
-#pragma unroll
-        for (int x = 0; x < 6; x++)
-#pragma unroll
-            for (int b = 0; b < 6; b++)
-                acc[x * 6 + b] += y[x * 3] * h[b * 3] + y[x * 3 + 1] * h[b * 3 + 1] + y[x * 3 + 2] * h[b * 3 + 2];
-    }
+    ba_pair_accumulate(a.ps_obs, a.obs_point, a.lookup, a.L, ba_recs{a.rec}, k1, k2, begin, end, acc);
     ba_block_sum<36>(acc, sw, out);
-    if (threadIdx.x < 36) a.W[((size_t)k1 * a.K + k2) * 36 + threadIdx.x] = out[threadIdx.x];
+    if (threadIdx.x < 36) a.W[(size_t)slot * 36 + threadIdx.x] = out[threadIdx.x];
+}
+
+// sum of the nsub slices of one entry, in slice order (stride = entries per slice block)
+__device__ __forceinline__ double bg_slices(const double* __restrict__ p, int nsub, int stride) {
+    double v = p[0];
+    for (int s = 1; s < nsub; s++) v += p[(size_t)s * stride];
+    return v;
+}
+
+// one value of wave-uniform lane `src` to every lane (two v_readlane_b32, no LDS round trip)
+__device__ __forceinline__ double bg_lane_bcast(double v, int src) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+
+// Workgroup 0's dense solve of the reduced system: S (LDS, lower triangle packed by rows, n = 6 * free poses <= 96) and
+// rhs (LDS) in, the solution in rhs out; false when S is not positive definite or the solution is not finite.
+//
+// L D L^T in place, right-looking, in PANELS of six columns (one pose block), two workgroup barriers per panel:
+//   (a) every thread factors the panel's 6 x 6 diagonal block for itself in registers (the same 21 LDS words, the same
+//       arithmetic: no barrier to hand it round), the thread that owns row r below the block solves that row's six L
+//       entries against it, stores them over S[r][panel] and keeps t = L D of the row in Tp (the unscaled column values
+//       the trailing update multiplies by);
+//   (b) the trailing triangle takes S[i][k] -= sum_c L[i][c] t[k][c] on a 16 x 16 thread tile, each thread holding the t
+//       rows of its (up to six) columns in registers.
+// The operations on every element, and their order, are those of the column-by-column form this replaces (one column and
+// two barriers per step: 15 us at n = 30, 81 us at n = 84, measured with tools/ba_phase_probe.py), so the factors are
+// the same bits.  The two substitutions run in wave 0 with the right-hand side in registers (lane i holds rows i and
+// i + 64) and one v_readlane pair per step instead of an LDS write + read.
+__device__ __forceinline__ bool bg_factor_solve(double* __restrict__ S, double* __restrict__ rhs, double* __restrict__ Tp, const int n) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ty = tid >> 4, tx = tid & 15;
+    bool spd = true;
+    for (int c0 = 0; c0 < n; c0 += 6) {
+        // (a) the diagonal block: D[a][b], b <= a, becomes (unscaled column values | pivots); inv[] = 1 / pivot
+        double D[6][6], inv[6];
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+            for (int b = 0; b <= a; b++) D[a][b] = S[BG_TRI(c0 + a, c0 + b)];
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            const double d = D[j][j];
+            spd = spd && d > 0.0 && isfinite(d);
+            inv[j] = 1.0 / d;
+#pragma unroll
+            for (int i = j + 1; i < 6; i++) {
+                const double lij = D[i][j] * inv[j];
+#pragma unroll
+                for (int k = j + 1; k <= i; k++) D[i][k] -= lij * D[k][j];
+            }
+        }
+        const int r = c0 + tid;
+        if (r < n && tid >= 6) {
+            {
+                double A[6];
+#pragma unroll
+                for (int b = 0; b < 6; b++) A[b] = S[BG_TRI(r, c0 + b)];
+#pragma unroll
+                for (int c = 0; c < 6; c++) {
+                    const double l = A[c] * inv[c];
+                    Tp[r * 6 + c] = A[c];
+                    S[BG_TRI(r, c0 + c)] = l;
+#pragma unroll
+                    for (int b = c + 1; b < 6; b++) A[b] -= l * D[b][c];
+                }
+            }
+        }
+        __syncthreads();
+        // the block's own rows: the pivot, and what lies left of it scaled (only now: every thread has read the block above)
+#pragma unroll
+        for (int a = 1; a < 6; a++)
+            if (tid == a) {
+#pragma unroll
+                for (int b = 0; b < a; b++) S[BG_TRI(c0 + a, c0 + b)] = D[a][b] * inv[b];
+                S[BG_TRI(c0 + a, c0 + a)] = D[a][a];
+            }
+        // (b) the trailing triangle, rows and columns from c0 + 6
+        const int m0 = c0 + 6;
+        if (m0 < n) {
+            double tk[6][6];
+#pragma unroll
+            for (int b = 0; b < 6; b++) {
+                const int k = m0 + tx + 16 * b;
+                if (k < n) {
+#pragma unroll
+                    for (int c = 0; c < 6; c++) tk[b][c] = Tp[k * 6 + c];
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < 6; a++) {
+                const int i = m0 + ty + 16 * a;
+                if (i < n) {
+                    double l[6];
+#pragma unroll
+                    for (int c = 0; c < 6; c++) l[c] = S[BG_TRI(i, c0 + c)];
+#pragma unroll
+                    for (int b = 0; b < 6; b++) {
+                        const int k = m0 + tx + 16 * b;
+                        if (k <= i) {
+                            double v = S[BG_TRI(i, k)];
+#pragma unroll
+                            for (int c = 0; c < 6; c++) v -= l[c] * tk[b][c];
+                            S[BG_TRI(i, k)] = v;
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    bool ok = true;
+    if (wave == 0) {
+        const int i0 = lane, i1 = lane + 64;
+        double r0 = i0 < n ? rhs[i0] : 0.0, r1 = i1 < n ? rhs[i1] : 0.0;
+        for (int j0 = 0; j0 < n; j0 += 6) {                   // forward: L y = rhs
+            double s0[6], s1[6];
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+                const int j = j0 + c;
+                s0[c] = (i0 > j && i0 < n) ? S[BG_TRI(i0, j)] : 0.0;
+                s1[c] = (i1 > j && i1 < n) ? S[BG_TRI(i1, j)] : 0.0;
+            }
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+                const int j = j0 + c;
+                const double yj = j < 64 ? bg_lane_bcast(r0, j) : bg_lane_bcast(r1, j - 64);
+                r0 -= s0[c] * yj;
+                r1 -= s1[c] * yj;
+            }
+        }
+        if (i0 < n) r0 /= S[BG_TRI(i0, i0)];
+        if (i1 < n) r1 /= S[BG_TRI(i1, i1)];
+        for (int j0 = n - 6; j0 >= 0; j0 -= 6) {              // backward: L^T x = y
+            double s0[6], s1[6];
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+                const int j = j0 + c;
+                s0[c] = i0 < j ? S[BG_TRI(j, i0)] : 0.0;
+                s1[c] = i1 < j ? S[BG_TRI(j, i1)] : 0.0;
+            }
+#pragma unroll
+            for (int c = 5; c >= 0; c--) {
+                const int j = j0 + c;
+                const double xj = j < 64 ? bg_lane_bcast(r0, j) : bg_lane_bcast(r1, j - 64);
+                r0 -= s0[c] * xj;
+                r1 -= s1[c] * xj;
+            }
+        }
+        const bool finite = (i0 >= n || isfinite(r0)) && (i1 >= n || isfinite(r1));
+        ok = __ballot(!(spd && finite)) == 0ull;
+        if (i0 < n) rhs[i0] = r0;
+        if (i1 < n) rhs[i1] = r1;
+    }
+    return ok;     // meaningful in wave 0 (thread 0 publishes it)
 }
 
 // exp([w, v]) * T for a 3x4 row-major pose (rotation first): the update the Jacobian of frontend.py:288-291 is the derivative for
@@ -520,13 +690,19 @@ __device__ void bg_apply_update(const double* dx, const double* T, double* Tn) {
 __global__ __launch_bounds__(BA_THREADS) void ba_lm_grid_kernel(const bg_args a) {
     __shared__ double S[BG_TRI(BG_MAXN, 0)];       // block 0: the reduced system, lower triangle packed by rows (37 KiB at 96 x 96)
     __shared__ double rhs[BG_MAXN];
+    __shared__ double Tp[BG_MAXN * 6];              // block 0: L D of the panel being eliminated
     __shared__ double sw[4][36];
     __shared__ double out[36];
     __shared__ int s_solved;
     __shared__ double sTn[64 * 12];                // the candidate poses, per workgroup (K <= 64)
+    __shared__ double sdp[64 * 6];                 // and the pose steps they come from
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, blk = (int)blockIdx.x, G = a.nblocks;
-    const int K = a.K, L = a.L, O = a.O, nf = a.nfree, n = 6 * nf;
+    const int K = a.K, L = a.L, O = a.O, nf = a.nfree, n = 6 * nf, nsub = a.nsub;
+    // the one-thread-per-item phases give every workgroup an equal share of the items (a phase is bound by what ONE
+    // compute unit can pull from memory behind the barrier, so it is spread over all of them, not packed 256 to a workgroup)
+    const int perO = (O + G - 1) / G, perL = (L + G - 1) / G;
     bg_ctl* c = a.ctl;
+    const ba_recs R = {a.rec};
     unsigned int gen = 0;
     // The Levenberg-Marquardt state is REPLICATED: every thread of every workgroup holds it and updates it with the same
     // arithmetic on the same device-memory values (read behind a grid barrier), so no verdict has to be published and
@@ -549,25 +725,32 @@ __global__ __launch_bounds__(BA_THREADS) void ba_lm_grid_kernel(const bg_args a)
 
         // ---- linearise at the state (only when it changed: a rejected trial only changes lambda) ----------------------------
         if (need_lin) {
-            for (int b = blk; b * BA_THREADS < O; b += G)
-                ba_obs_body(T, X, a.obs_pose, a.obs_point, a.meas, O, a.cam, a.delta, K, L, a.index_errors, a.rec, b);
+            for (int o = blk * perO + tid; o < min(O, (blk + 1) * perO); o += BA_THREADS)
+                ba_obs_body(T, X, a.obs_pose, a.obs_point, a.meas, O, a.cam, a.delta, K, L, a.index_errors, R, o);
             if (!bg_grid_sync(c, G, gen)) return;
             need_lin = 0;
         }
         // ---- points: Hll, bl, E = (Hll + lambda I)^-1, Y = Hpl E ---------------------------------------------------------------
-        for (int b = blk; b * BA_THREADS < L; b += G) ba_point_body(a.pt_ptr, a.pt_obs, L, lam, a.rec, a.E, a.bl, a.hll, b);
+        for (int l = blk * perL + tid; l < min(L, (blk + 1) * perL); l += BA_THREADS)
+            ba_point_body(a.pt_ptr, a.pt_obs, L, lam, R, a.E, a.bl, a.hll, l);
         if (!bg_grid_sync(c, G, gen)) return;
-        // ---- per pose: Hpp, bp, y, cost; per pair of free poses: W (one workgroup per task) ---------------------------------------
+        // ---- per pose: Hpp, bp, y, cost; per pair of free poses: W.  A task (a pose's, or a pair's first pose's, observation
+        //      list) is cut into nsub slices, one workgroup each; the consumers add the slices up in slice order -----------------
         {
-            const int npair = nf * (nf + 1) / 2;
-            for (int task = blk; task < K + npair; task += G) {
-                if (task < K) {
-                    ba_pose_body(a.ps_ptr, a.ps_obs, a.obs_point, a.rec, a.bl, a.Hpp, a.bp, a.ybl, a.costk, (double(*)[34])sw, out, task);
-                } else {
+            const int npair = nf * (nf + 1) / 2, ntask = K + npair;
+            for (int t = blk; t < ntask * nsub; t += G) {
+                const int task = t % ntask, sl = t / ntask;
+                int k1, k2 = -1;
+                if (task < K) k1 = task;
+                else {
                     int p = task - K, f1 = 0;
                     while (p >= nf - f1) { p -= nf - f1; f1++; }
-                    bg_pair(a, a.free_list[f1], a.free_list[f1 + p], sw, out);
+                    k1 = a.free_list[f1]; k2 = a.free_list[f1 + p];
                 }
+                const int p0 = a.ps_ptr[k1], p1 = a.ps_ptr[k1 + 1], len = (p1 - p0 + nsub - 1) / nsub;
+                const int begin = min(p1, p0 + sl * len), end = min(p1, begin + len);
+                if (task < K) ba_pose_body(a.ps_obs, a.obs_point, R, a.bl, a.Hpp, a.bp, a.ybl, a.costk, (double(*)[34])sw, out, begin, end, sl * K + k1);
+                else bg_pair(a, k1, k2, begin, end, sl * npair + (task - K), sw, out);
                 __syncthreads();
             }
         }
@@ -580,7 +763,7 @@ __global__ __launch_bounds__(BA_THREADS) void ba_lm_grid_kernel(const bg_args a)
             for (int i = tid; i < L * 3; i += BA_THREADS) v = fmax(v, a.hll[i]);
             for (int i = tid; i < nf * 6; i += BA_THREADS) {
                 const int d = i % 6;
-                v = fmax(v, a.Hpp[(size_t)a.free_list[i / 6] * 21 + d * 6 - d * (d - 1) / 2]);   // diagonal entry d of the packed upper triangle
+                v = fmax(v, bg_slices(a.Hpp + (size_t)a.free_list[i / 6] * 21 + d * 6 - d * (d - 1) / 2, nsub, K * 21));   // diagonal entry d of the packed upper triangle
             }
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
@@ -589,7 +772,7 @@ __global__ __launch_bounds__(BA_THREADS) void ba_lm_grid_kernel(const bg_args a)
             __syncthreads();
             lambda = 1e-5 * fmax(fmax(fmax(sw[0][0], sw[1][0]), fmax(sw[2][0], sw[3][0])), 1e-12);
             cost = 0.0;
-            for (int k = 0; k < K; k++) cost += a.costk[k];
+            for (int k = 0; k < K; k++) cost += bg_slices(a.costk + k, nsub, K);
             if (blk == 0 && tid == 0) a.stats[0] = cost;
             if (a.iterations <= 0 || nf == 0) done = 1;
             __syncthreads();
@@ -598,78 +781,29 @@ __global__ __launch_bounds__(BA_THREADS) void ba_lm_grid_kernel(const bg_args a)
 
         // ---- workgroup 0: assemble the reduced system of the free poses in LDS and solve it -----------------------------------
         if (blk == 0) {
+            const int npair = nf * (nf + 1) / 2;
             for (int idx = tid; idx < n * n; idx += BA_THREADS) {
                 const int i = idx / n, j = idx % n, fa = i / 6, fb = j / 6, ii = i % 6, jj = j % 6;
                 if (j > i) continue;                       // S is symmetric: the lower triangle is kept
-                const int ka = a.free_list[fa], kb = a.free_list[fb];
+                const int pidx = fb * nf - fb * (fb - 1) / 2 + (fa - fb);          // the pair (fb <= fa) in the order the tasks run
                 double v;
                 if (fa == fb) {
                     const int tri = jj * 6 - jj * (jj - 1) / 2 + (ii - jj);        // jj <= ii: index in the packed upper triangle of Hpp
-                    v = a.Hpp[(size_t)ka * 21 + tri] + (ii == jj ? lam : 0.0) - a.W[((size_t)ka * K + ka) * 36 + ii * 6 + jj];
+                    v = bg_slices(a.Hpp + (size_t)a.free_list[fa] * 21 + tri, nsub, K * 21) + (ii == jj ? lam : 0.0) -
+                        bg_slices(a.W + (size_t)pidx * 36 + ii * 6 + jj, nsub, npair * 36);
                 } else {
-                    v = -a.W[((size_t)kb * K + ka) * 36 + jj * 6 + ii];            // fa > fb: the transpose of W[kb, ka]
+                    v = -bg_slices(a.W + (size_t)pidx * 36 + jj * 6 + ii, nsub, npair * 36);   // fa > fb: the transpose of W[kb, ka]
                 }
                 S[BG_TRI(i, j)] = v;
             }
+            for (int i = tid; i < K * 6; i += BA_THREADS) a.bpc[i] = bg_slices(a.bp + i, nsub, K * 6);
             for (int i = tid; i < n; i += BA_THREADS) {
-                const int k = a.free_list[i / 6];
-                rhs[i] = -a.bp[(size_t)k * 6 + i % 6] + a.ybl[(size_t)k * 6 + i % 6];
+                const size_t e = (size_t)a.free_list[i / 6] * 6 + i % 6;
+                rhs[i] = -bg_slices(a.bp + e, nsub, K * 6) + bg_slices(a.ybl + e, nsub, K * 6);
             }
             __syncthreads();
-            // L D L^T in place, right-looking, the whole workgroup: step j subtracts (S[i][j] / d_j) S[k][j] from every
-            // element (i, k) of the trailing triangle (a 16 x 16 thread tile walks it; column j is only read), then scales
-            // column j.  After step j column j below the diagonal holds L, the diagonal D.  (A first version gave each lane
-            // of ONE wave two rows: its inner loop is a chain of dependent LDS read-modify-writes and took ~55 us at 30 x 30.)
-            bool spd = true;
-            {
-                const int ty = tid >> 4, tx = tid & 15;
-                for (int j = 0; j < n; j++) {
-                    const double d = S[BG_TRI(j, j)];
-                    spd = spd && d > 0.0 && isfinite(d);
-                    const double inv = 1.0 / d;
-                    for (int i = j + 1 + ty; i < n; i += 16) {
-                        const double lij = S[BG_TRI(i, j)] * inv;
-                        for (int k = j + 1 + tx; k <= i; k += 16) S[BG_TRI(i, k)] -= lij * S[BG_TRI(k, j)];
-                    }
-                    __syncthreads();
-                    for (int i = j + 1 + tid; i < n; i += BA_THREADS) S[BG_TRI(i, j)] *= inv;
-                    __syncthreads();
-                }
-            }
-            if (wave == 0) {
-                for (int j = 0; j < n; j++) {            // forward: L y = rhs
-                    const double yj = rhs[j];
-#pragma unroll
-                    for (int half = 0; half < 2; half++) {
-                        const int i = lane + 64 * half;
-                        if (i > j && i < n) rhs[i] -= S[BG_TRI(i, j)] * yj;
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                }
-#pragma unroll
-                for (int half = 0; half < 2; half++) {
-                    const int i = lane + 64 * half;
-                    if (i < n) rhs[i] /= S[BG_TRI(i, i)];
-                }
-                __builtin_amdgcn_wave_barrier();
-                for (int j = n - 1; j >= 0; j--) {        // backward: L^T x = y
-                    const double xj = rhs[j];
-#pragma unroll
-                    for (int half = 0; half < 2; half++) {
-                        const int i = lane + 64 * half;
-                        if (i < j) rhs[i] -= S[BG_TRI(j, i)] * xj;
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                }
-                bool finite = true;
-#pragma unroll
-                for (int half = 0; half < 2; half++) {
-                    const int i = lane + 64 * half;
-                    if (i < n) finite = finite && isfinite(rhs[i]);
-                }
-                const bool ok = __ballot(!(spd && finite)) == 0ull;
-                if (lane == 0) s_solved = ok ? 1 : 0;
-            }
+            const bool ok = bg_factor_solve(S, rhs, Tp, n);
+            if (tid == 0) s_solved = ok ? 1 : 0;
             __syncthreads();
             for (int i = tid; i < K * 6; i += BA_THREADS) a.dp[i] = 0.0;
             __syncthreads();
@@ -688,47 +822,61 @@ __global__ __launch_bounds__(BA_THREADS) void ba_lm_grid_kernel(const bg_args a)
         //      share of the gain ratio's denominator, and the candidate's robust cost over the point's observations (every
         //      workgroup keeps the K candidate poses in LDS; workgroup 0 also stores them) --------------------------------------
         {
+            for (int i = tid; i < K * 6; i += BA_THREADS) sdp[i] = a.dp[i];
+            __syncthreads();
             for (int k = tid; k < K; k += BA_THREADS) {
-                bg_apply_update(a.dp + (size_t)k * 6, T + (size_t)k * 12, sTn + (size_t)k * 12);
+                bg_apply_update(sdp + (size_t)k * 6, T + (size_t)k * 12, sTn + (size_t)k * 12);
                 if (blk == 0)
                     for (int x = 0; x < 12; x++) Tn[(size_t)k * 12 + x] = sTn[(size_t)k * 12 + x];
             }
             __syncthreads();
             double sc = 0.0, cc = 0.0;
-            for (int b = blk; b * BA_THREADS < L; b += G) {
-                ba_backsub_body(a.pt_ptr, a.pt_obs, a.obs_pose, L, a.rec, a.E, a.bl, a.dp, a.dl, b);
-                const int l = b * BA_THREADS + tid;
-                if (l < L) {
-                    double p[3];
+            for (int l = blk * perL + tid; l < min(L, (blk + 1) * perL); l += BA_THREADS) {
+                // dl = E (-bl - sum_{o of l} Hpl_o^T dp_pose(o)) as ba_backsub_body has it, the pose steps read from LDS
+                const int a0 = a.pt_ptr[l], a1 = a.pt_ptr[l + 1];
+                double t[3], bl3[3];
 #pragma unroll
-                    for (int x = 0; x < 3; x++) {
-                        const double d = a.dl[(size_t)l * 3 + x];          // this thread's own store
-                        p[x] = X[(size_t)l * 3 + x] + d;
-                        Xn[(size_t)l * 3 + x] = p[x];
-                        sc += d * (lam * d - a.bl[(size_t)l * 3 + x]);
+                for (int x = 0; x < 3; x++) { bl3[x] = a.bl[(size_t)l * 3 + x]; t[x] = -bl3[x]; }
+                for (int i = a0; i < a1; i++) {
+                    const int o = a.pt_obs[i];
+                    const ba_rec_ref r = R.of(o);
+                    const double* d = sdp + (size_t)a.obs_pose[o] * 6;
+#pragma unroll
+                    for (int cI = 0; cI < 3; cI++)
+#pragma unroll
+                        for (int aI = 0; aI < 6; aI++) t[cI] -= r[aI * 3 + cI] * d[aI];
+                }
+                const double* e = a.E + (size_t)l * 9;
+                double p[3];
+#pragma unroll
+                for (int x = 0; x < 3; x++) {
+                    const double d = a1 > a0 ? e[x * 3] * t[0] + e[x * 3 + 1] * t[1] + e[x * 3 + 2] * t[2] : 0.0;
+                    a.dl[(size_t)l * 3 + x] = d;
+                    p[x] = X[(size_t)l * 3 + x] + d;
+                    Xn[(size_t)l * 3 + x] = p[x];
+                    sc += d * (lam * d - bl3[x]);
+                }
+                for (int i = a0; i < a1; i++) {
+                    const int o = a.pt_obs[i];
+                    const double* P = sTn + (size_t)a.obs_pose[o] * 12;
+                    const double Xc = P[0] * p[0] + P[1] * p[1] + P[2] * p[2] + P[3];
+                    const double Yc = P[4] * p[0] + P[5] * p[1] + P[6] * p[2] + P[7];
+                    const double Zc = P[8] * p[0] + P[9] * p[1] + P[10] * p[2] + P[11];
+                    const double2 m = a.meas[o];
+                    const double e0 = m.x - (a.cam.fx * Xc + a.cam.cx * Zc) / Zc;
+                    const double e1 = m.y - (a.cam.fy * Yc + a.cam.cy * Zc) / Zc;
+                    const double c2 = e0 * e0 + e1 * e1;
+                    double rho = c2;
+                    if (a.delta > 0.0) {
+                        const double en = sqrt(c2);
+                        if (en > a.delta) rho = 2.0 * a.delta * en - a.delta * a.delta;
                     }
-                    for (int i = a.pt_ptr[l]; i < a.pt_ptr[l + 1]; i++) {
-                        const int o = a.pt_obs[i];
-                        const double* P = sTn + (size_t)a.obs_pose[o] * 12;
-                        const double Xc = P[0] * p[0] + P[1] * p[1] + P[2] * p[2] + P[3];
-                        const double Yc = P[4] * p[0] + P[5] * p[1] + P[6] * p[2] + P[7];
-                        const double Zc = P[8] * p[0] + P[9] * p[1] + P[10] * p[2] + P[11];
-                        const double2 m = a.meas[o];
-                        const double e0 = m.x - (a.cam.fx * Xc + a.cam.cx * Zc) / Zc;
-                        const double e1 = m.y - (a.cam.fy * Yc + a.cam.cy * Zc) / Zc;
-                        const double c2 = e0 * e0 + e1 * e1;
-                        double rho = c2;
-                        if (a.delta > 0.0) {
-                            const double en = sqrt(c2);
-                            if (en > a.delta) rho = 2.0 * a.delta * en - a.delta * a.delta;
-                        }
-                        cc += rho;
-                    }
+                    cc += rho;
                 }
             }
             if (blk == 0)
                 for (int k = tid; k < K; k += BA_THREADS)
-                    for (int x = 0; x < 6; x++) sc += a.dp[(size_t)k * 6 + x] * (lam * a.dp[(size_t)k * 6 + x] - a.bp[(size_t)k * 6 + x]);
+                    for (int x = 0; x < 6; x++) sc += sdp[(size_t)k * 6 + x] * (lam * sdp[(size_t)k * 6 + x] - a.bpc[(size_t)k * 6 + x]);
             double acc[2] = {sc, cc};
             ba_block_sum<2>(acc, (double(*)[2])sw, out);
             if (tid == 0) { a.part[2 * blk] = out[0]; a.part[2 * blk + 1] = out[1]; }
@@ -770,21 +918,35 @@ __global__ __launch_bounds__(BA_THREADS) void ba_lm_grid_kernel(const bg_args a)
 
 static inline uint64_t bg_round16(uint64_t b) { return (b + 15) / 16 * 16; }
 
-// number of workgroups of the persistent launch: enough for one task each in the widest phase, at most 128
-static int bg_blocks(int64_t K, int64_t L, int64_t O, int64_t n_free) {
-    int64_t want = K + n_free * (n_free + 1) / 2;
-    if ((O + BA_THREADS - 1) / BA_THREADS > want) want = (O + BA_THREADS - 1) / BA_THREADS;
-    if ((L + BA_THREADS - 1) / BA_THREADS > want) want = (L + BA_THREADS - 1) / BA_THREADS;
-    return (int)(want < 8 ? 8 : (want > 128 ? 128 : want));
+#define BG_MAX_BLOCKS 128
+#define BG_MAX_SLICES 8
+#define BG_MAX_PAIRS (SLAM_BA_LM_MAX_FREE * (SLAM_BA_LM_MAX_FREE + 1) / 2)
+
+// Number of workgroups of the persistent launch, and the slices a pose / pair task is cut into.  Measured at the
+// reference's window (7 keyframes, 5792 observations; tools/ba_phase_probe.py, us per accepted step incl. five barriers):
+// 23 workgroups (one per task) 81, 46 (two slices per task) 77.5, 61 77.3, 121 (five slices) 92 - the camera-block phase
+// shrinks with the slices (21 -> 15 -> 12 us), but every workgroup re-reads the same few lines (poses, lists' heads) behind
+// each barrier and workgroup 0 adds the slices up before it can solve (assembly 4 -> 15 us at five slices).  Hence about
+// 128 observations per workgroup, at least one workgroup per task, at most 128 (half the device: all of them must be
+// resident at once), and as many slices as that width gives a workgroup each, at most 8.
+static void bg_shape(int64_t K, int64_t O, int64_t n_free, int* blocks, int* slices) {
+    const int64_t ntask = K + n_free * (n_free + 1) / 2;
+    int64_t want = (O + 127) / 128;
+    if (want < ntask) want = ntask;
+    want = want < 8 ? 8 : (want > BG_MAX_BLOCKS ? BG_MAX_BLOCKS : want);
+    int64_t ns = want / ntask;
+    *blocks = (int)want;
+    *slices = (int)(ns < 1 ? 1 : (ns > BG_MAX_SLICES ? BG_MAX_SLICES : ns));
 }
 
 extern "C" int slam_ba_optimize_workspace(int64_t K, int64_t L, int64_t O, uint64_t* bytes) {
     SLAM_REQUIRE(bytes, "slam_ba_optimize_workspace: null pointer");
     SLAM_REQUIRE(K >= 1 && K <= 64 && L >= 1 && L <= (1 << 24) && O >= 0 && O <= SLAM_BA_LM_MAX_OBS, "bad sizes");
+    const uint64_t ks = (uint64_t)K * BG_MAX_SLICES;
     *bytes = bg_round16(sizeof(bg_ctl)) + bg_round16((uint64_t)K * L * 4) + bg_round16((uint64_t)(O ? O : 1) * BA_REC * 8) +
-             bg_round16((uint64_t)L * 72) + 2 * bg_round16((uint64_t)L * 24) + bg_round16((uint64_t)K * 168) + 2 * bg_round16((uint64_t)K * 48) +
-             2 * bg_round16((uint64_t)K * 8) + bg_round16((uint64_t)K * K * 288) + bg_round16((uint64_t)K * 48) + bg_round16((uint64_t)L * 24) +
-             bg_round16(2 * 128 * 8);
+             bg_round16((uint64_t)L * 72) + 2 * bg_round16((uint64_t)L * 24) + bg_round16(ks * 168) + 2 * bg_round16(ks * 48) +
+             bg_round16(ks * 8) + bg_round16((uint64_t)K * 48) + bg_round16((uint64_t)BG_MAX_PAIRS * BG_MAX_SLICES * 288) +
+             bg_round16((uint64_t)K * 48) + bg_round16((uint64_t)L * 24) + bg_round16(2 * BG_MAX_BLOCKS * 8);
     return SLAM_OK;
 }
 
@@ -810,7 +972,7 @@ extern "C" int slam_ba_optimize_f64(slam_ctx* ctx, int64_t K, int64_t L, int64_t
     SLAM_HIP(hipSetDevice(ctx->device));
     bg_args a;
     a.K = (int)K; a.L = (int)L; a.O = (int)O; a.iterations = iterations; a.nfree = (int)n_free;
-    a.nblocks = bg_blocks(K, L, O, n_free);
+    bg_shape(K, O, n_free, &a.nblocks, &a.nsub);
     a.obs_pose = d_obs_pose; a.obs_point = d_obs_point; a.meas = (const double2*)d_meas;
     a.pt_ptr = d_pt_ptr; a.pt_obs = d_pt_obs; a.ps_ptr = d_ps_ptr; a.ps_obs = d_ps_obs; a.free_list = d_free_poses;
     a.T = d_poses2; a.X = d_points2;
@@ -820,11 +982,12 @@ extern "C" int slam_ba_optimize_f64(slam_ctx* ctx, int64_t K, int64_t L, int64_t
     a.lookup = (int*)take((uint64_t)K * L * 4);
     a.rec = (double*)take((uint64_t)(O ? O : 1) * BA_REC * 8);
     a.E = (double*)take((uint64_t)L * 72); a.bl = (double*)take((uint64_t)L * 24); a.hll = (double*)take((uint64_t)L * 24);
-    a.Hpp = (double*)take((uint64_t)K * 168); a.bp = (double*)take((uint64_t)K * 48); a.ybl = (double*)take((uint64_t)K * 48);
-    a.costk = (double*)take((uint64_t)K * 8); a.costn = (double*)take((uint64_t)K * 8);
-    a.W = (double*)take((uint64_t)K * K * 288);
+    const uint64_t ks = (uint64_t)K * BG_MAX_SLICES;
+    a.Hpp = (double*)take(ks * 168); a.bp = (double*)take(ks * 48); a.ybl = (double*)take(ks * 48);
+    a.costk = (double*)take(ks * 8); a.bpc = (double*)take((uint64_t)K * 48);
+    a.W = (double*)take((uint64_t)BG_MAX_PAIRS * BG_MAX_SLICES * 288);
     a.dp = (double*)take((uint64_t)K * 48); a.dl = (double*)take((uint64_t)L * 24);
-    a.part = (double*)take(2 * 128 * 8);
+    a.part = (double*)take(2 * BG_MAX_BLOCKS * 8);
     a.stats = d_stats;
     a.index_errors = slam_index_error_counter(ctx);
     a.cam = {fx, fy, cx, cy};

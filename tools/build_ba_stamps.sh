@@ -1,0 +1,35 @@
+#!/bin/bash
+# Experiment build of libslamhip.so for tools/ba_phase_probe.py (development aid; nothing in the product or the tests
+# loads it): ba_schur.hip with wall_clock64() stamps (100 MHz) by thread 0 of every workgroup of the one-launch window
+# LM before and after every grid barrier, and by workgroup 0 around the parts of the reduced solve.
+set -euo pipefail
+ROOT="$(cd "$(dirname "$0")/.." && pwd)"
+SRC="$ROOT/slam-experiments_amd/csrc"
+OUT="$ROOT/tools/exp"
+TMP="$(mktemp -d)"
+mkdir -p "$OUT"
+make -C "$SRC" -j8 all >/dev/null
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$ROOT/include -I/opt/rocm/include -I$SRC -fvisibility=hidden -DSLAM_BUILD"
+OBJS=$(ls "$ROOT"/slam-experiments_amd/lib/obj/*.o | grep -v ba_schur)
+python3 - "$SRC/ba_schur.hip" "$TMP/ba_stamps.hip" <<'PY'
+import sys
+s = open(sys.argv[1]).read()
+bar = 'if (!bg_grid_sync(c, G, gen)) return;'
+n = s.count(bar)
+assert n >= 6, "the barrier hooks did not apply: the kernel source changed"
+s = s.replace(bar, 'BG_ST(); ' + bar + ' BG_ST();')
+s = s.replace('    unsigned int gen = 0;\n', '    unsigned int gen = 0;\n    int sidx = 0, s2idx = 0;\n    BG_ST();\n', 1)
+mark = '            const bool ok = bg_factor_solve(S, rhs, Tp, n);\n'
+assert s.count(mark) == 1, "the solve hook did not apply"
+s = s.replace(mark, '            BG_ST2();\n' + mark + '            BG_ST2();\n', 1)
+s = s.replace('#define BA_THREADS 256\n', '#define BA_THREADS 256\n__device__ unsigned long long* g_st = nullptr;\n'
+              'extern "C" __attribute__((visibility("default"))) int slam_exp_set_ba_stamps(void* p) '
+              '{ return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_st), &p, sizeof(p)); }\n'
+              '#define BG_ST() do { if (tid == 0 && g_st && sidx < 200) g_st[blk * 256 + sidx] = wall_clock64(); sidx++; } while (0)\n'
+              '#define BG_ST2() do { if (tid == 0 && g_st && s2idx < 56) g_st[blk * 256 + 200 + s2idx] = wall_clock64(); s2idx++; } while (0)\n', 1)
+open(sys.argv[2], 'w').write(s)
+PY
+/opt/rocm/bin/hipcc $FLAGS -c "$TMP/ba_stamps.hip" -o "$TMP/ba_stamps.o"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libslamhip_bastamps.so" "$TMP/ba_stamps.o" $OBJS -ldl
+rm -rf "$TMP"
+ls -la "$OUT/libslamhip_bastamps.so"
