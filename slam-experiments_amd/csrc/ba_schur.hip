@@ -57,6 +57,36 @@ __device__ __forceinline__ double ba_wave_sum(double v) {
 
 // (the *_body functions take the block index as an argument: blockIdx.x of the per-phase kernels below, a loop variable
 // of the persistent kernel in ba_lm.hip's grid form at the end of this file)
+// one observation linearised: residual e, robust weight w and cost rho, the 2x6 pose Jacobian (rotation first) and the 2x3
+// point Jacobian, at pose P (3x4 row-major, any address space) and point p
+struct ba_lin { double e0, e1, w, rho, jp[2][6], jq[2][3]; };
+
+__device__ __forceinline__ void ba_linearise(const double* P, const double* p, const double2 m, const ba_cam& cam, const double delta,
+                                             ba_lin& q) {
+    const double X = P[0] * p[0] + P[1] * p[1] + P[2] * p[2] + P[3];
+    const double Y = P[4] * p[0] + P[5] * p[1] + P[6] * p[2] + P[7];
+    const double Z = P[8] * p[0] + P[9] * p[1] + P[10] * p[2] + P[11];
+    q.e0 = m.x - (cam.fx * X + cam.cx * Z) / Z;      // frontend.py:275-277
+    q.e1 = m.y - (cam.fy * Y + cam.cy * Z) / Z;
+    const double Zinv = 1.0 / (Z + 1e-18), Zinv2 = Zinv * Zinv;  // frontend.py:284-291
+    q.jp[0][0] = cam.fx * X * Y * Zinv2; q.jp[0][1] = -cam.fx - cam.fx * X * X * Zinv2; q.jp[0][2] = cam.fx * Y * Zinv;
+    q.jp[0][3] = -cam.fx * Zinv; q.jp[0][4] = 0.0; q.jp[0][5] = cam.fx * X * Zinv2;
+    q.jp[1][0] = cam.fy + cam.fy * Y * Y * Zinv2; q.jp[1][1] = -cam.fy * X * Y * Zinv2; q.jp[1][2] = -cam.fy * X * Zinv;
+    q.jp[1][3] = 0.0; q.jp[1][4] = -cam.fy * Zinv; q.jp[1][5] = cam.fy * Y * Zinv2;
+    const double A[2][3] = {{cam.fx * Zinv, 0.0, -cam.fx * X * Zinv2}, {0.0, cam.fy * Zinv, -cam.fy * Y * Zinv2}};
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        q.jq[0][c] = -(A[0][0] * P[c] + A[0][2] * P[8 + c]);
+        q.jq[1][c] = -(A[1][1] * P[4 + c] + A[1][2] * P[8 + c]);
+    }
+    const double c2 = q.e0 * q.e0 + q.e1 * q.e1;
+    q.w = 1.0; q.rho = c2;
+    if (delta > 0.0) {
+        const double en = sqrt(c2);
+        if (en > delta) { q.w = delta / en; q.rho = 2.0 * delta * en - delta * delta; }
+    }
+}
+
 __device__ __forceinline__ void ba_obs_body(const double* __restrict__ poses, const double* __restrict__ points,
                                             const int* __restrict__ obs_pose, const int* __restrict__ obs_point,
                                             const double2* __restrict__ meas, int O, ba_cam cam, double delta, int K, int L,
@@ -68,33 +98,13 @@ __device__ __forceinline__ void ba_obs_body(const double* __restrict__ poses, co
         atomicAdd(index_errors, 1u);
         k = 0; l = 0; bad = true;
     }
-    const double* P = poses + (size_t)k * 12;
-    const double* p = points + (size_t)l * 3;
-    const double X = P[0] * p[0] + P[1] * p[1] + P[2] * p[2] + P[3];
-    const double Y = P[4] * p[0] + P[5] * p[1] + P[6] * p[2] + P[7];
-    const double Z = P[8] * p[0] + P[9] * p[1] + P[10] * p[2] + P[11];
     double2 m = meas[o];
     if (bad) m.x = m.y = __builtin_nan("");
-    const double e0 = m.x - (cam.fx * X + cam.cx * Z) / Z;      // frontend.py:275-277
-    const double e1 = m.y - (cam.fy * Y + cam.cy * Z) / Z;
-    const double Zinv = 1.0 / (Z + 1e-18), Zinv2 = Zinv * Zinv;  // frontend.py:284-291
-    const double jp[2][6] = {{cam.fx * X * Y * Zinv2, -cam.fx - cam.fx * X * X * Zinv2, cam.fx * Y * Zinv,
-                              -cam.fx * Zinv, 0.0, cam.fx * X * Zinv2},
-                             {cam.fy + cam.fy * Y * Y * Zinv2, -cam.fy * X * Y * Zinv2, -cam.fy * X * Zinv, 0.0,
-                              -cam.fy * Zinv, cam.fy * Y * Zinv2}};
-    const double A[2][3] = {{cam.fx * Zinv, 0.0, -cam.fx * X * Zinv2}, {0.0, cam.fy * Zinv, -cam.fy * Y * Zinv2}};
-    double jq[2][3];
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-        jq[0][c] = -(A[0][0] * P[c] + A[0][2] * P[8 + c]);
-        jq[1][c] = -(A[1][1] * P[4 + c] + A[1][2] * P[8 + c]);
-    }
-    const double c2 = e0 * e0 + e1 * e1;
-    double w = 1.0, rho = c2;
-    if (delta > 0.0) {
-        const double en = sqrt(c2);
-        if (en > delta) { w = delta / en; rho = 2.0 * delta * en - delta * delta; }
-    }
+    ba_lin q;
+    ba_linearise(poses + (size_t)k * 12, points + (size_t)l * 3, m, cam, delta, q);
+    const double e0 = q.e0, e1 = q.e1, w = q.w, rho = q.rho;
+    const double (&jp)[2][6] = q.jp;
+    const double (&jq)[2][3] = q.jq;
     const ba_rec_ref r = rec.of(o);
 #pragma unroll
     for (int a = 0; a < 6; a++)
@@ -128,6 +138,18 @@ __global__ __launch_bounds__(BA_THREADS) void ba_obs_kernel(const double* __rest
     ba_obs_body(poses, points, obs_pose, obs_point, meas, O, cam, delta, K, L, index_errors, ba_recs{rec}, (int)(blockIdx.x * BA_THREADS + threadIdx.x));
 }
 
+// symmetric 3x3 inverse of H + lam I, H as its packed upper triangle (the identity for a point nobody observes)
+__device__ __forceinline__ void ba_damped_inverse(const double (&h)[6], const double lam, const bool seen, double (&e)[9]) {
+    double m00 = h[0] + lam, m01 = h[1], m02 = h[2], m11 = h[3] + lam, m12 = h[4], m22 = h[5] + lam;
+    if (!seen) { m00 = m11 = m22 = 1.0; m01 = m02 = m12 = 0.0; }
+    const double c00 = m11 * m22 - m12 * m12, c01 = m02 * m12 - m01 * m22, c02 = m01 * m12 - m02 * m11;
+    const double det = m00 * c00 + m01 * c01 + m02 * c02;
+    const double id = 1.0 / det;
+    e[0] = c00 * id; e[1] = c01 * id; e[2] = c02 * id;
+    e[3] = e[1]; e[4] = (m00 * m22 - m02 * m02) * id; e[5] = (m01 * m02 - m00 * m12) * id;
+    e[6] = e[2]; e[7] = e[5]; e[8] = (m00 * m11 - m01 * m01) * id;
+}
+
 // per point: Hll, bl over its observations (CSR row, ascending), E = (Hll + lam I)^-1, Y_o = Hpl_o E
 __device__ __forceinline__ void ba_point_body(const int* __restrict__ pt_ptr, const int* __restrict__ pt_obs, int L, double lam,
                                               const ba_recs rec, double* __restrict__ E, double* __restrict__ bl,
@@ -142,16 +164,8 @@ __device__ __forceinline__ void ba_point_body(const int* __restrict__ pt_ptr, co
 #pragma unroll
         for (int k = 0; k < 3; k++) b[k] += r[69 + k];
     }
-    // symmetric 3x3 inverse of H + lam I (identity for a point nobody observes)
-    double m00 = h[0] + lam, m01 = h[1], m02 = h[2], m11 = h[3] + lam, m12 = h[4], m22 = h[5] + lam;
-    if (a1 == a0) { m00 = m11 = m22 = 1.0; m01 = m02 = m12 = 0.0; }
-    const double c00 = m11 * m22 - m12 * m12, c01 = m02 * m12 - m01 * m22, c02 = m01 * m12 - m02 * m11;
-    const double det = m00 * c00 + m01 * c01 + m02 * c02;
-    const double id = 1.0 / det;
     double e[9];
-    e[0] = c00 * id; e[1] = c01 * id; e[2] = c02 * id;
-    e[3] = e[1]; e[4] = (m00 * m22 - m02 * m02) * id; e[5] = (m01 * m02 - m00 * m12) * id;
-    e[6] = e[2]; e[7] = e[5]; e[8] = (m00 * m11 - m01 * m01) * id;
+    ba_damped_inverse(h, lam, a1 > a0, e);
 #pragma unroll
     for (int k = 0; k < 9; k++) E[(size_t)l * 9 + k] = e[k];
 #pragma unroll
@@ -426,12 +440,20 @@ extern "C" int slam_ba_backsub_f64(slam_ctx* ctx, int64_t L, const int32_t* d_pt
 // =====================================================================================================================
 // The whole window LM as ONE persistent launch of a few dozen workgroups (slam_ba_optimize_f64).
 //
-// Same phases as the per-phase kernels above - their bodies are called with a loop variable for the block index - but
-// nothing returns to the host between them: a grid barrier separates the phases, workgroup 0 assembles the reduced
-// system of the free poses in LDS and factors it (L D L^T, one wave), and the Levenberg-Marquardt bookkeeping is
-// replicated in every workgroup (same arithmetic on the same values), so a verdict costs no barrier of its own:
-// five barriers per accepted trial (linearise | points | camera blocks | solve | step + candidate cost), four per
-// rejected one.
+// Nothing returns to the host between the phases: a grid barrier separates them, workgroup 0 assembles the reduced system
+// of the free poses in LDS and factors it, and the Levenberg-Marquardt bookkeeping is replicated in every workgroup
+// (same arithmetic on the same values), so a verdict costs no barrier of its own.
+//
+// Unlike the per-phase kernels above this form keeps NO per-observation records: every phase linearises the observations
+// it touches again (ba_linearise: ~150 flops from the pose in LDS, the point and the measurement - 7 doubles read instead
+// of up to 46 of a 584-byte record, and no phase that writes them).  Behind a grid barrier every read comes from memory,
+// and the record traffic was what the phases cost (~17 ns per observation and compute unit, tools/ba_phase_probe.py); the
+// arithmetic is free beside it.  Four barriers per trial:
+//   points         one thread per point: Hll, bl over its observations, E = (Hll + lambda I)^-1
+//   camera blocks  a workgroup per slice of a pose's observation list: Hpp, bp, y = sum Y bl, cost; and per slice of a pair
+//                  of free poses: W = sum Y_(k1,l) Hpl_(k2,l)^T, both observations linearised on the spot
+//   solve          workgroup 0: the reduced system from the slices, L D L^T, the pose steps
+//   step           one thread per point: dl by back-substitution, the candidate point, the candidate's robust cost
 //
 // The grid barrier is the counter hand-off of cdna_hip_programming.md G16: every wave drains its stores, the
 // workgroup's barrier, then ONE lane does an agent-scope release, takes a ticket, and either opens the next generation
@@ -453,7 +475,7 @@ struct bg_args {
     const int* pt_ptr; const int* pt_obs; const int* ps_ptr; const int* ps_obs; const int* free_list;
     int* lookup;
     double* T; double* X;                                        // [2][K*12], [2][L*3]
-    double* rec; double* E; double* bl; double* hll;             // [O*BA_REC], [L*9], [L*3], [L*3]
+    double* E; double* bl; double* hll;                          // [L*9], [L*3], [L*3]
     // per pose and slice (slot k * nsub + s): [.*21] [.*6] [.*6] [.]; per pair of free poses and slice: [.*36]; bpc [K*6]:
     // the slices of bp added up (workgroup 0, with the solve), for the gain ratio's denominator
     double* Hpp; double* bp; double* ybl; double* costk; double* bpc; double* W;
@@ -496,12 +518,132 @@ __device__ __forceinline__ bool bg_grid_sync(bg_ctl* c, unsigned int nblocks, un
     return bg_load(&c->abort) == 0;
 }
 
+// Hpl = w Jp^T Jq (6x3) of a linearised observation
+__device__ __forceinline__ void bg_hpl(const ba_lin& q, double (&h)[6][3]) {
+#pragma unroll
+    for (int x = 0; x < 6; x++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) h[x][c] = q.w * (q.jp[0][x] * q.jq[0][c] + q.jp[1][x] * q.jq[1][c]);
+}
+
+// slice [begin, end) of pose k's observation list: Hpp (21), bp (6), y = sum Y_o bl (6), cost (1), stored as block `slot`
+// (what ba_obs_body + ba_pose_body do through the records)
+__device__ __forceinline__ void bg_pose(const bg_args& a, const double* __restrict__ X, const double* sT, int k, int begin, int end, int slot,
+                                        double (*sw)[34], double* out) {
+    double acc[34];
+#pragma unroll
+    for (int i = 0; i < 34; i++) acc[i] = 0.0;
+    // Four strides of the list at a time, level by level: entry -> observation -> (point, measurement) -> (point, E, bl).
+    // With a few dozen entries per thread the phase is a chain of dependent memory latencies (every read behind the grid
+    // barrier comes from memory), and walking one entry at a time pays the chain once per entry.  Indices are clamped into
+    // the slice, the surplus is masked where it is added; the sums take their terms in the list's order either way.
+    for (int base = begin + threadIdx.x; base < end; base += 4 * BA_THREADS) {
+        int o[4], l[4];
+        double2 m[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) o[u] = a.ps_obs[min(base + u * BA_THREADS, end - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { l[u] = a.obs_point[o[u]]; m[u] = a.meas[o[u]]; }
+        double x[4][3], e[4][9], b[4][3];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) { x[u][c] = X[(size_t)l[u] * 3 + c]; b[u][c] = a.bl[(size_t)l[u] * 3 + c]; }
+#pragma unroll
+            for (int c = 0; c < 9; c++) e[u][c] = a.E[(size_t)l[u] * 9 + c];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (base + u * BA_THREADS >= end) break;
+            ba_lin q;
+            ba_linearise(sT + (size_t)k * 12, x[u], m[u], a.cam, a.delta, q);
+            int t = 0;
+#pragma unroll
+            for (int r = 0; r < 6; r++)
+#pragma unroll
+                for (int c = r; c < 6; c++) acc[t++] += q.w * (q.jp[0][r] * q.jp[0][c] + q.jp[1][r] * q.jp[1][c]);
+#pragma unroll
+            for (int r = 0; r < 6; r++) acc[21 + r] += q.w * (q.jp[0][r] * q.e0 + q.jp[1][r] * q.e1);
+            double h[6][3];
+            bg_hpl(q, h);
+#pragma unroll
+            for (int r = 0; r < 6; r++) {
+                const double y0 = h[r][0] * e[u][0] + h[r][1] * e[u][3] + h[r][2] * e[u][6], y1 = h[r][0] * e[u][1] + h[r][1] * e[u][4] + h[r][2] * e[u][7],
+                             y2 = h[r][0] * e[u][2] + h[r][1] * e[u][5] + h[r][2] * e[u][8];
+                acc[27 + r] += y0 * b[u][0] + y1 * b[u][1] + y2 * b[u][2];
+            }
+            acc[33] += q.rho;
+        }
+    }
+    ba_block_sum<34>(acc, sw, out);
+    if (threadIdx.x < 21) a.Hpp[(size_t)slot * 21 + threadIdx.x] = out[threadIdx.x];
+    if (threadIdx.x < 6) {
+        a.bp[(size_t)slot * 6 + threadIdx.x] = out[21 + threadIdx.x];
+        a.ybl[(size_t)slot * 6 + threadIdx.x] = out[27 + threadIdx.x];
+    }
+    if (threadIdx.x == 0) a.costk[slot] = out[33];
+}
+
 // slice [begin, end) of k1's list towards the W block of one pair of poses (k1 <= k2), see ba_pair_body; stored as block `slot`
-__device__ __forceinline__ void bg_pair(const bg_args& a, int k1, int k2, int begin, int end, int slot, double (*sw)[36], double* out) {
+__device__ __forceinline__ void bg_pair(const bg_args& a, const double* __restrict__ X, const double* sT, int k1, int k2, int begin, int end,
+                                        int slot, double (*sw)[36], double* out) {
     double acc[36];
 #pragma unroll
     for (int i = 0; i < 36; i++) acc[i] = 0.0;
-    ba_pair_accumulate(a.ps_obs, a.obs_point, a.lookup, a.L, ba_recs{a.rec}, k1, k2, begin, end, acc);
+    // four strides at a time, level by level (see bg_pose): entry -> observation -> (point, measurement) -> (partner, point, E)
+    // -> the partner's measurement
+    for (int base = begin + threadIdx.x; base < end; base += 4 * BA_THREADS) {
+        int o1[4], l[4], o2[4];
+        double2 m1[4], m2[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) o1[u] = a.ps_obs[min(base + u * BA_THREADS, end - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { l[u] = a.obs_point[o1[u]]; m1[u] = a.meas[o1[u]]; }
+        double x[4][3], e[4][9];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            o2[u] = k1 == k2 ? o1[u] : a.lookup[(size_t)k2 * a.L + l[u]];
+#pragma unroll
+            for (int c = 0; c < 3; c++) x[u][c] = X[(size_t)l[u] * 3 + c];
+#pragma unroll
+            for (int c = 0; c < 9; c++) e[u][c] = a.E[(size_t)l[u] * 9 + c];
+        }
+        if (k1 != k2) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) m2[u] = a.meas[max(o2[u], 0)];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (base + u * BA_THREADS >= end) break;
+            if (o2[u] < 0) continue;
+            double y[6][3], h2[6][3];
+            {
+                ba_lin q;
+                ba_linearise(sT + (size_t)k1 * 12, x[u], m1[u], a.cam, a.delta, q);
+                double h1[6][3];
+                bg_hpl(q, h1);
+#pragma unroll
+                for (int r = 0; r < 6; r++)
+#pragma unroll
+                    for (int c = 0; c < 3; c++) y[r][c] = h1[r][0] * e[u][c] + h1[r][1] * e[u][3 + c] + h1[r][2] * e[u][6 + c];
+                if (k1 == k2) {
+#pragma unroll
+                    for (int r = 0; r < 6; r++)
+#pragma unroll
+                        for (int c = 0; c < 3; c++) h2[r][c] = h1[r][c];
+                }
+            }
+            if (k1 != k2) {
+                ba_lin q;
+                ba_linearise(sT + (size_t)k2 * 12, x[u], m2[u], a.cam, a.delta, q);
+                bg_hpl(q, h2);
+            }
+#pragma unroll
+            for (int r = 0; r < 6; r++)
+#pragma unroll
+                for (int b = 0; b < 6; b++) acc[r * 6 + b] += y[r][0] * h2[b][0] + y[r][1] * h2[b][1] + y[r][2] * h2[b][2];
+        }
+    }
     ba_block_sum<36>(acc, sw, out);
     if (threadIdx.x < 36) a.W[(size_t)slot * 36 + threadIdx.x] = out[threadIdx.x];
 }
@@ -517,6 +659,15 @@ __device__ __forceinline__ double bg_slices(const double* __restrict__ p, int ns
 __device__ __forceinline__ double bg_lane_bcast(double v, int src) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
     return __hiloint2double(hi, lo);
+}
+
+// 1 / d for a pivot: v_rcp_f64 (about 24 good bits) and two Newton steps, five dependent instructions where the IEEE
+// division sequence has about thirty - the 6 n pivots of a factorisation are one dependent chain, and at n = 30 the
+// divisions were a third of it.  The result is within an ulp or two of 1 / d; the factors feed an iterative LM step.
+__device__ __forceinline__ double bg_reciprocal(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    return fma(fma(-d, r, 1.0), r, r);
 }
 
 // Workgroup 0's dense solve of the reduced system: S (LDS, lower triangle packed by rows, n = 6 * free poses <= 96) and
@@ -547,7 +698,7 @@ __device__ __forceinline__ bool bg_factor_solve(double* __restrict__ S, double* 
         for (int j = 0; j < 6; j++) {
             const double d = D[j][j];
             spd = spd && d > 0.0 && isfinite(d);
-            inv[j] = 1.0 / d;
+            inv[j] = bg_reciprocal(d);
 #pragma unroll
             for (int i = j + 1; i < 6; i++) {
                 const double lij = D[i][j] * inv[j];
@@ -687,6 +838,17 @@ __device__ void bg_apply_update(const double* dx, const double* T, double* Tn) {
     }
 }
 
+// up to eight observations of a point's row, their poses and measurements, loaded level by level (entry -> observation ->
+// (pose, measurement)): indices clamped into the row, the surplus to be masked by the caller (see bg_pose)
+struct bg_row8 { int k[8]; double2 m[8]; };
+__device__ __forceinline__ void bg_load_row8(const bg_args& a, int base, int a1, bg_row8& c) {
+    int o[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) o[u] = a.pt_obs[min(base + u, a1 - 1)];
+#pragma unroll
+    for (int u = 0; u < 8; u++) { c.k[u] = a.obs_pose[o[u]]; c.m[u] = a.meas[o[u]]; }
+}
+
 __global__ __launch_bounds__(BA_THREADS) void ba_lm_grid_kernel(const bg_args a) {
     __shared__ double S[BG_TRI(BG_MAXN, 0)];       // block 0: the reduced system, lower triangle packed by rows (37 KiB at 96 x 96)
     __shared__ double rhs[BG_MAXN];
@@ -694,26 +856,35 @@ __global__ __launch_bounds__(BA_THREADS) void ba_lm_grid_kernel(const bg_args a)
     __shared__ double sw[4][36];
     __shared__ double out[36];
     __shared__ int s_solved;
-    __shared__ double sTn[64 * 12];                // the candidate poses, per workgroup (K <= 64)
+    __shared__ double sT[64 * 12];                 // the poses of the state, per workgroup (K <= 64)
+    __shared__ double sTn[64 * 12];                // the candidate poses
     __shared__ double sdp[64 * 6];                 // and the pose steps they come from
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, blk = (int)blockIdx.x, G = a.nblocks;
     const int K = a.K, L = a.L, O = a.O, nf = a.nfree, n = 6 * nf, nsub = a.nsub;
     // the one-thread-per-item phases give every workgroup an equal share of the items (a phase is bound by what ONE
     // compute unit can pull from memory behind the barrier, so it is spread over all of them, not packed 256 to a workgroup)
-    const int perO = (O + G - 1) / G, perL = (L + G - 1) / G;
+    const int perL = (L + G - 1) / G;
     bg_ctl* c = a.ctl;
-    const ba_recs R = {a.rec};
     unsigned int gen = 0;
     // The Levenberg-Marquardt state is REPLICATED: every thread of every workgroup holds it and updates it with the same
     // arithmetic on the same device-memory values (read behind a grid barrier), so no verdict has to be published and
     // waited for - only the factorisation's outcome (workgroup 0's) travels through the control block.
-    int cur = 0, need_lin = 1, accepted = 0, trials = 0, iter = 0, trial = 0, done = 0;
+    int cur = 0, accepted = 0, trials = 0, iter = 0, trial = 0, done = 0;
     double lambda = -1.0, ni = 2.0, cost = 0.0;      // lambda < 0: "not measured yet"
 
-    // ---- phase 0: the (pose, point) -> observation table, on the device ---------------------------------------------------
+    // ---- phase 0: the (pose, point) -> observation table, on the device; an index outside the window is counted
+    //      (slam_index_errors) and ends the launch: every later phase trusts the two index arrays -------------------------------
     for (long long i = (long long)blk * BA_THREADS + tid; i < (long long)K * L; i += (long long)G * BA_THREADS) a.lookup[i] = -1;
     if (!bg_grid_sync(c, G, gen)) return;
-    for (int o = blk * BA_THREADS + tid; o < O; o += G * BA_THREADS) a.lookup[(size_t)a.obs_pose[o] * L + a.obs_point[o]] = o;
+    for (int o = blk * BA_THREADS + tid; o < O; o += G * BA_THREADS) {
+        const int k = a.obs_pose[o], l = a.obs_point[o];
+        if ((unsigned)k >= (unsigned)K || (unsigned)l >= (unsigned)L) {
+            atomicAdd(a.index_errors, 1u);
+            __hip_atomic_store(&c->abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            a.lookup[(size_t)k * L + l] = o;
+        }
+    }
     if (!bg_grid_sync(c, G, gen)) return;
 
     while (!done) {
@@ -723,34 +894,58 @@ __global__ __launch_bounds__(BA_THREADS) void ba_lm_grid_kernel(const bg_args a)
         double* Tn = a.T + (size_t)(1 - cur) * K * 12;
         double* Xn = a.X + (size_t)(1 - cur) * L * 3;
 
-        // ---- linearise at the state (only when it changed: a rejected trial only changes lambda) ----------------------------
-        if (need_lin) {
-            for (int o = blk * perO + tid; o < min(O, (blk + 1) * perO); o += BA_THREADS)
-                ba_obs_body(T, X, a.obs_pose, a.obs_point, a.meas, O, a.cam, a.delta, K, L, a.index_errors, R, o);
-            if (!bg_grid_sync(c, G, gen)) return;
-            need_lin = 0;
+        for (int i = tid; i < K * 12; i += BA_THREADS) sT[i] = T[i];
+        __syncthreads();
+        // ---- points: Hll, bl over the point's observations, E = (Hll + lambda I)^-1 ---------------------------------------------
+        for (int l = blk * perL + tid; l < min(L, (blk + 1) * perL); l += BA_THREADS) {
+            const int a0 = a.pt_ptr[l], a1 = a.pt_ptr[l + 1];
+            double x[3], h[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
+#pragma unroll
+            for (int cI = 0; cI < 3; cI++) x[cI] = X[(size_t)l * 3 + cI];
+            for (int base = a0; base < a1; base += 8) {
+                bg_row8 row;
+                bg_load_row8(a, base, a1, row);
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    if (base + u >= a1) break;
+                    ba_lin q;
+                    ba_linearise(sT + (size_t)row.k[u] * 12, x, row.m[u], a.cam, a.delta, q);
+                    int t = 0;
+#pragma unroll
+                    for (int r = 0; r < 3; r++)
+#pragma unroll
+                        for (int cI = r; cI < 3; cI++) h[t++] += q.w * (q.jq[0][r] * q.jq[0][cI] + q.jq[1][r] * q.jq[1][cI]);
+#pragma unroll
+                    for (int r = 0; r < 3; r++) b[r] += q.w * (q.jq[0][r] * q.e0 + q.jq[1][r] * q.e1);
+                }
+            }
+            double e[9];
+            ba_damped_inverse(h, lam, a1 > a0, e);
+#pragma unroll
+            for (int i = 0; i < 9; i++) a.E[(size_t)l * 9 + i] = e[i];
+#pragma unroll
+            for (int i = 0; i < 3; i++) a.bl[(size_t)l * 3 + i] = b[i];
+            a.hll[(size_t)l * 3] = h[0]; a.hll[(size_t)l * 3 + 1] = h[3]; a.hll[(size_t)l * 3 + 2] = h[5];
         }
-        // ---- points: Hll, bl, E = (Hll + lambda I)^-1, Y = Hpl E ---------------------------------------------------------------
-        for (int l = blk * perL + tid; l < min(L, (blk + 1) * perL); l += BA_THREADS)
-            ba_point_body(a.pt_ptr, a.pt_obs, L, lam, R, a.E, a.bl, a.hll, l);
         if (!bg_grid_sync(c, G, gen)) return;
         // ---- per pose: Hpp, bp, y, cost; per pair of free poses: W.  A task (a pose's, or a pair's first pose's, observation
-        //      list) is cut into nsub slices, one workgroup each; the consumers add the slices up in slice order -----------------
+        //      list) is cut into nsub slices, one workgroup each; the consumers add the slices up in slice order.  The very
+        //      first pass only measures the diagonal and the cost: it runs the pose tasks alone --------------------------------
         {
-            const int npair = nf * (nf + 1) / 2, ntask = K + npair;
+            const int npair = nf * (nf + 1) / 2, ntask = lambda < 0.0 ? K : K + npair;
             for (int t = blk; t < ntask * nsub; t += G) {
                 const int task = t % ntask, sl = t / ntask;
                 int k1, k2 = -1;
                 if (task < K) k1 = task;
                 else {
-                    int p = task - K, f1 = 0;
-                    while (p >= nf - f1) { p -= nf - f1; f1++; }
-                    k1 = a.free_list[f1]; k2 = a.free_list[f1 + p];
+                    int pi = task - K, f1 = 0;
+                    while (pi >= nf - f1) { pi -= nf - f1; f1++; }
+                    k1 = a.free_list[f1]; k2 = a.free_list[f1 + pi];
                 }
                 const int p0 = a.ps_ptr[k1], p1 = a.ps_ptr[k1 + 1], len = (p1 - p0 + nsub - 1) / nsub;
                 const int begin = min(p1, p0 + sl * len), end = min(p1, begin + len);
-                if (task < K) ba_pose_body(a.ps_obs, a.obs_point, R, a.bl, a.Hpp, a.bp, a.ybl, a.costk, (double(*)[34])sw, out, begin, end, sl * K + k1);
-                else bg_pair(a, k1, k2, begin, end, sl * npair + (task - K), sw, out);
+                if (task < K) bg_pose(a, X, sT, k1, begin, end, sl * K + k1, (double(*)[34])sw, out);
+                else bg_pair(a, X, sT, k1, k2, begin, end, sl * npair + (task - K), sw, out);
                 __syncthreads();
             }
         }
@@ -782,9 +977,11 @@ __global__ __launch_bounds__(BA_THREADS) void ba_lm_grid_kernel(const bg_args a)
         // ---- workgroup 0: assemble the reduced system of the free poses in LDS and solve it -----------------------------------
         if (blk == 0) {
             const int npair = nf * (nf + 1) / 2;
-            for (int idx = tid; idx < n * n; idx += BA_THREADS) {
-                const int i = idx / n, j = idx % n, fa = i / 6, fb = j / 6, ii = i % 6, jj = j % 6;
-                if (j > i) continue;                       // S is symmetric: the lower triangle is kept
+            for (int idx = tid; idx < BG_TRI(n, 0); idx += BA_THREADS) {     // S is symmetric: the lower triangle is kept, packed by rows
+                int i = (int)((sqrtf(8.0f * (float)idx + 1.0f) - 1.0f) * 0.5f);
+                while (BG_TRI(i, 0) > idx) i--;
+                while (BG_TRI(i + 1, 0) <= idx) i++;
+                const int j = idx - BG_TRI(i, 0), fa = i / 6, fb = j / 6, ii = i % 6, jj = j % 6;
                 const int pidx = fb * nf - fb * (fb - 1) / 2 + (fa - fb);          // the pair (fb <= fa) in the order the tasks run
                 double v;
                 if (fa == fb) {
@@ -794,7 +991,7 @@ __global__ __launch_bounds__(BA_THREADS) void ba_lm_grid_kernel(const bg_args a)
                 } else {
                     v = -bg_slices(a.W + (size_t)pidx * 36 + jj * 6 + ii, nsub, npair * 36);   // fa > fb: the transpose of W[kb, ka]
                 }
-                S[BG_TRI(i, j)] = v;
+                S[idx] = v;
             }
             for (int i = tid; i < K * 6; i += BA_THREADS) a.bpc[i] = bg_slices(a.bp + i, nsub, K * 6);
             for (int i = tid; i < n; i += BA_THREADS) {
@@ -832,19 +1029,32 @@ __global__ __launch_bounds__(BA_THREADS) void ba_lm_grid_kernel(const bg_args a)
             __syncthreads();
             double sc = 0.0, cc = 0.0;
             for (int l = blk * perL + tid; l < min(L, (blk + 1) * perL); l += BA_THREADS) {
-                // dl = E (-bl - sum_{o of l} Hpl_o^T dp_pose(o)) as ba_backsub_body has it, the pose steps read from LDS
+                // dl = E (-bl - sum_{o of l} Hpl_o^T dp_pose(o)) as ba_backsub_body has it, Hpl linearised again, the pose steps from LDS
                 const int a0 = a.pt_ptr[l], a1 = a.pt_ptr[l + 1];
                 double t[3], bl3[3];
 #pragma unroll
                 for (int x = 0; x < 3; x++) { bl3[x] = a.bl[(size_t)l * 3 + x]; t[x] = -bl3[x]; }
-                for (int i = a0; i < a1; i++) {
-                    const int o = a.pt_obs[i];
-                    const ba_rec_ref r = R.of(o);
-                    const double* d = sdp + (size_t)a.obs_pose[o] * 6;
+                double x0[3];
 #pragma unroll
-                    for (int cI = 0; cI < 3; cI++)
+                for (int cI = 0; cI < 3; cI++) x0[cI] = X[(size_t)l * 3 + cI];
+                bg_row8 first = {};                             // the row's first eight observations serve both loops
+                if (a1 > a0) bg_load_row8(a, a0, a1, first);
+                for (int base = a0; base < a1; base += 8) {
+                    bg_row8 row = first;
+                    if (base > a0) bg_load_row8(a, base, a1, row);
 #pragma unroll
-                        for (int aI = 0; aI < 6; aI++) t[cI] -= r[aI * 3 + cI] * d[aI];
+                    for (int u = 0; u < 8; u++) {
+                        if (base + u >= a1) break;
+                        ba_lin q;
+                        ba_linearise(sT + (size_t)row.k[u] * 12, x0, row.m[u], a.cam, a.delta, q);
+                        double h[6][3];
+                        bg_hpl(q, h);
+                        const double* d = sdp + (size_t)row.k[u] * 6;
+#pragma unroll
+                        for (int cI = 0; cI < 3; cI++)
+#pragma unroll
+                            for (int aI = 0; aI < 6; aI++) t[cI] -= h[aI][cI] * d[aI];
+                    }
                 }
                 const double* e = a.E + (size_t)l * 9;
                 double p[3];
@@ -852,26 +1062,30 @@ __global__ __launch_bounds__(BA_THREADS) void ba_lm_grid_kernel(const bg_args a)
                 for (int x = 0; x < 3; x++) {
                     const double d = a1 > a0 ? e[x * 3] * t[0] + e[x * 3 + 1] * t[1] + e[x * 3 + 2] * t[2] : 0.0;
                     a.dl[(size_t)l * 3 + x] = d;
-                    p[x] = X[(size_t)l * 3 + x] + d;
+                    p[x] = x0[x] + d;
                     Xn[(size_t)l * 3 + x] = p[x];
                     sc += d * (lam * d - bl3[x]);
                 }
-                for (int i = a0; i < a1; i++) {
-                    const int o = a.pt_obs[i];
-                    const double* P = sTn + (size_t)a.obs_pose[o] * 12;
-                    const double Xc = P[0] * p[0] + P[1] * p[1] + P[2] * p[2] + P[3];
-                    const double Yc = P[4] * p[0] + P[5] * p[1] + P[6] * p[2] + P[7];
-                    const double Zc = P[8] * p[0] + P[9] * p[1] + P[10] * p[2] + P[11];
-                    const double2 m = a.meas[o];
-                    const double e0 = m.x - (a.cam.fx * Xc + a.cam.cx * Zc) / Zc;
-                    const double e1 = m.y - (a.cam.fy * Yc + a.cam.cy * Zc) / Zc;
-                    const double c2 = e0 * e0 + e1 * e1;
-                    double rho = c2;
-                    if (a.delta > 0.0) {
-                        const double en = sqrt(c2);
-                        if (en > a.delta) rho = 2.0 * a.delta * en - a.delta * a.delta;
+                for (int base = a0; base < a1; base += 8) {
+                    bg_row8 row = first;
+                    if (base > a0) bg_load_row8(a, base, a1, row);
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        if (base + u >= a1) break;
+                        const double* P = sTn + (size_t)row.k[u] * 12;
+                        const double Xc = P[0] * p[0] + P[1] * p[1] + P[2] * p[2] + P[3];
+                        const double Yc = P[4] * p[0] + P[5] * p[1] + P[6] * p[2] + P[7];
+                        const double Zc = P[8] * p[0] + P[9] * p[1] + P[10] * p[2] + P[11];
+                        const double e0 = row.m[u].x - (a.cam.fx * Xc + a.cam.cx * Zc) / Zc;
+                        const double e1 = row.m[u].y - (a.cam.fy * Yc + a.cam.cy * Zc) / Zc;
+                        const double c2 = e0 * e0 + e1 * e1;
+                        double rho = c2;
+                        if (a.delta > 0.0) {
+                            const double en = sqrt(c2);
+                            if (en > a.delta) rho = 2.0 * a.delta * en - a.delta * a.delta;
+                        }
+                        cc += rho;
                     }
-                    cc += rho;
                 }
             }
             if (blk == 0)
@@ -891,7 +1105,6 @@ __global__ __launch_bounds__(BA_THREADS) void ba_lm_grid_kernel(const bg_args a)
             if (rho > 0.0 && isfinite(cc)) {
                 cur = 1 - cur;                             // the candidate buffers become the state
                 cost = cc;
-                need_lin = 1;
                 const double g = 2.0 * rho - 1.0;
                 lambda = lam * fmax(1.0 / 3.0, fmin(1.0 - g * g * g, 2.0 / 3.0));
                 ni = 2.0;
@@ -923,15 +1136,15 @@ static inline uint64_t bg_round16(uint64_t b) { return (b + 15) / 16 * 16; }
 #define BG_MAX_PAIRS (SLAM_BA_LM_MAX_FREE * (SLAM_BA_LM_MAX_FREE + 1) / 2)
 
 // Number of workgroups of the persistent launch, and the slices a pose / pair task is cut into.  Measured at the
-// reference's window (7 keyframes, 5792 observations; tools/ba_phase_probe.py, us per accepted step incl. five barriers):
-// 23 workgroups (one per task) 81, 46 (two slices per task) 77.5, 61 77.3, 121 (five slices) 92 - the camera-block phase
-// shrinks with the slices (21 -> 15 -> 12 us), but every workgroup re-reads the same few lines (poses, lists' heads) behind
-// each barrier and workgroup 0 adds the slices up before it can solve (assembly 4 -> 15 us at five slices).  Hence about
-// 128 observations per workgroup, at least one workgroup per task, at most 128 (half the device: all of them must be
-// resident at once), and as many slices as that width gives a workgroup each, at most 8.
+// reference's window (7 keyframes, 5792 observations, 22 tasks; tools/ba_phase_probe.py, us per accepted step incl. its
+// four barriers): 22 workgroups 59.4, 46 (two slices per task) 62.2, 61 65, 91 73, 121 80 - the camera-block phase shrinks
+// with the slices (15.5 -> 13 -> 11 us), but the point phase grows with the number of workgroups (6.6 -> 9 -> 16 us: each
+// re-reads the poses and the lists' heads behind every barrier) and workgroup 0 adds the slices up before it can solve.
+// Hence one workgroup per task, more only when the lists are long (about 512 observations per workgroup), at most 128
+// (half the device: all of them must be resident at once), and as many slices as that width gives a workgroup each (<= 8).
 static void bg_shape(int64_t K, int64_t O, int64_t n_free, int* blocks, int* slices) {
     const int64_t ntask = K + n_free * (n_free + 1) / 2;
-    int64_t want = (O + 127) / 128;
+    int64_t want = (O + 511) / 512;
     if (want < ntask) want = ntask;
     want = want < 8 ? 8 : (want > BG_MAX_BLOCKS ? BG_MAX_BLOCKS : want);
     int64_t ns = want / ntask;
@@ -943,7 +1156,7 @@ extern "C" int slam_ba_optimize_workspace(int64_t K, int64_t L, int64_t O, uint6
     SLAM_REQUIRE(bytes, "slam_ba_optimize_workspace: null pointer");
     SLAM_REQUIRE(K >= 1 && K <= 64 && L >= 1 && L <= (1 << 24) && O >= 0 && O <= SLAM_BA_LM_MAX_OBS, "bad sizes");
     const uint64_t ks = (uint64_t)K * BG_MAX_SLICES;
-    *bytes = bg_round16(sizeof(bg_ctl)) + bg_round16((uint64_t)K * L * 4) + bg_round16((uint64_t)(O ? O : 1) * BA_REC * 8) +
+    *bytes = bg_round16(sizeof(bg_ctl)) + bg_round16((uint64_t)K * L * 4) +
              bg_round16((uint64_t)L * 72) + 2 * bg_round16((uint64_t)L * 24) + bg_round16(ks * 168) + 2 * bg_round16(ks * 48) +
              bg_round16(ks * 8) + bg_round16((uint64_t)K * 48) + bg_round16((uint64_t)BG_MAX_PAIRS * BG_MAX_SLICES * 288) +
              bg_round16((uint64_t)K * 48) + bg_round16((uint64_t)L * 24) + bg_round16(2 * BG_MAX_BLOCKS * 8);
@@ -980,7 +1193,6 @@ extern "C" int slam_ba_optimize_f64(slam_ctx* ctx, int64_t K, int64_t L, int64_t
     auto take = [&](uint64_t bytes) { char* p = w; w += bg_round16(bytes); return p; };
     a.ctl = (bg_ctl*)take(sizeof(bg_ctl));
     a.lookup = (int*)take((uint64_t)K * L * 4);
-    a.rec = (double*)take((uint64_t)(O ? O : 1) * BA_REC * 8);
     a.E = (double*)take((uint64_t)L * 72); a.bl = (double*)take((uint64_t)L * 24); a.hll = (double*)take((uint64_t)L * 24);
     const uint64_t ks = (uint64_t)K * BG_MAX_SLICES;
     a.Hpp = (double*)take(ks * 168); a.bp = (double*)take(ks * 48); a.ybl = (double*)take(ks * 48);

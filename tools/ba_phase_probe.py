@@ -82,12 +82,12 @@ for b in range(nb):
 s2 = tr[0, 200:]
 s2 = (s2[s2 > 0] - t0) * 0.01
 print("workgroup 0 solve stamps (assembled, solved) per solve:", " ".join(f"{v:.2f}" for v in s2))
-# per accepted iteration after the first (rows 9..: linearise | points | camera blocks | solve | step), averaged
-if nb >= 14 and (nb - 9) % 5 == 0:
-    names = ("linearise", "points", "camera blocks", "solve", "step")
-    work = np.zeros(5); bar = np.zeros(5); cnt = 0
-    for b0 in range(9, nb, 5):
-        for x in range(5):
+# per accepted iteration after the first (rows 8..: points | camera blocks | solve | step), averaged
+if nb >= 12 and (nb - 8) % 4 == 0:
+    names = ("points", "camera blocks", "solve", "step")
+    work = np.zeros(4); bar = np.zeros(4); cnt = 0
+    for b0 in range(8, nb, 4):
+        for x in range(4):
             b = b0 + x
             arrive, leave = us[:, 1 + 2 * b], us[:, 2 + 2 * b]
             before = us[:, 2 * b]
