@@ -734,24 +734,27 @@ __device__ __forceinline__ bool bg_factor_solve(double* __restrict__ S, double* 
         // (b) the trailing triangle, rows and columns from c0 + 6
         const int m0 = c0 + 6;
         if (m0 < n) {
+            // (the loop bounds below are wave-uniform - a tile row or column that starts beyond the matrix ends the loop for
+            // every thread alike, and a column tile right of the row tile holds no element of the lower triangle - so a small
+            // system skips the tiles it does not have instead of evaluating 36 empty predicates)
             double tk[6][6];
 #pragma unroll
             for (int b = 0; b < 6; b++) {
-                const int k = m0 + tx + 16 * b;
-                if (k < n) {
+                if (m0 + 16 * b >= n) break;
+                const int k = min(m0 + tx + 16 * b, n - 1);
 #pragma unroll
-                    for (int c = 0; c < 6; c++) tk[b][c] = Tp[k * 6 + c];
-                }
+                for (int c = 0; c < 6; c++) tk[b][c] = Tp[k * 6 + c];
             }
 #pragma unroll
             for (int a = 0; a < 6; a++) {
+                if (m0 + 16 * a >= n) break;
                 const int i = m0 + ty + 16 * a;
                 if (i < n) {
                     double l[6];
 #pragma unroll
                     for (int c = 0; c < 6; c++) l[c] = S[BG_TRI(i, c0 + c)];
 #pragma unroll
-                    for (int b = 0; b < 6; b++) {
+                    for (int b = 0; b <= a; b++) {
                         const int k = m0 + tx + 16 * b;
                         if (k <= i) {
                             double v = S[BG_TRI(i, k)];
@@ -769,18 +772,23 @@ __device__ __forceinline__ bool bg_factor_solve(double* __restrict__ S, double* 
     if (wave == 0) {
         const int i0 = lane, i1 = lane + 64;
         double r0 = i0 < n ? rhs[i0] : 0.0, r1 = i1 < n ? rhs[i1] : 0.0;
+        // (every lane loads from a clamped, always valid address and masks the value: twelve predicated LDS reads per panel,
+        // each in an exec-mask region of its own, were most of a step's time; likewise the row that holds step j is picked
+        // with a select, not a branch)
+        const int c0i = min(i0, n - 1), c1i = min(i1, n - 1);
         for (int j0 = 0; j0 < n; j0 += 6) {                   // forward: L y = rhs
             double s0[6], s1[6];
 #pragma unroll
             for (int c = 0; c < 6; c++) {
                 const int j = j0 + c;
-                s0[c] = (i0 > j && i0 < n) ? S[BG_TRI(i0, j)] : 0.0;
-                s1[c] = (i1 > j && i1 < n) ? S[BG_TRI(i1, j)] : 0.0;
+                const double v0 = S[BG_TRI(c0i, min(j, c0i))], v1 = S[BG_TRI(c1i, min(j, c1i))];
+                s0[c] = (i0 > j && i0 < n) ? v0 : 0.0;
+                s1[c] = (i1 > j && i1 < n) ? v1 : 0.0;
             }
 #pragma unroll
             for (int c = 0; c < 6; c++) {
                 const int j = j0 + c;
-                const double yj = j < 64 ? bg_lane_bcast(r0, j) : bg_lane_bcast(r1, j - 64);
+                const double yj = bg_lane_bcast(j < 64 ? r0 : r1, j & 63);
                 r0 -= s0[c] * yj;
                 r1 -= s1[c] * yj;
             }
@@ -792,13 +800,14 @@ __device__ __forceinline__ bool bg_factor_solve(double* __restrict__ S, double* 
 #pragma unroll
             for (int c = 0; c < 6; c++) {
                 const int j = j0 + c;
-                s0[c] = i0 < j ? S[BG_TRI(j, i0)] : 0.0;
-                s1[c] = i1 < j ? S[BG_TRI(j, i1)] : 0.0;
+                const double v0 = S[BG_TRI(j, min(i0, j))], v1 = S[BG_TRI(j, min(i1, j))];
+                s0[c] = i0 < j ? v0 : 0.0;
+                s1[c] = i1 < j ? v1 : 0.0;
             }
 #pragma unroll
             for (int c = 5; c >= 0; c--) {
                 const int j = j0 + c;
-                const double xj = j < 64 ? bg_lane_bcast(r0, j) : bg_lane_bcast(r1, j - 64);
+                const double xj = bg_lane_bcast(j < 64 ? r0 : r1, j & 63);
                 r0 -= s0[c] * xj;
                 r1 -= s1[c] * xj;
             }

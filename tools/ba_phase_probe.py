@@ -45,8 +45,8 @@ dT, dX = ctx.upload(state_T), ctx.upload(state_X)
 need = ctypes.c_uint64(0)
 ctx.lib.slam_ba_optimize_workspace(K, L, O, ctypes.byref(need))
 dW, dS = ctx.malloc(need.value), ctx.malloc(64)
-stamps = ctx.malloc(128 * 256 * 8)
-ctx.lib.slam_memset(ctx.handle, stamps.ptr, 0, 128 * 256 * 8)
+stamps = ctx.malloc((128 * 256 + 2048) * 8)
+ctx.lib.slam_memset(ctx.handle, stamps.ptr, 0, (128 * 256 + 2048) * 8)
 
 
 def run():
@@ -63,7 +63,8 @@ assert ctx.lib.slam_exp_set_ba_stamps(stamps.ptr) == 0
 ms = run()
 st = dS.download(np.float64, (8,))
 G = int(st[7])
-tr = stamps.download(np.uint64, (128, 256)).astype(np.int64)[:G]
+raw = stamps.download(np.uint64, (128 * 256 + 2048,)).astype(np.int64)
+tr = raw[:128 * 256].reshape(128, 256)[:G]
 n = int((tr[0, :200] > 0).sum())
 t0 = tr[:, 0].min()
 us = (tr - t0) * 0.01
@@ -95,3 +96,11 @@ if nb >= 12 and (nb - 8) % 4 == 0:
         cnt += 1
     print("per iteration: " + ", ".join(f"{n} {w / cnt:.1f} (+{q / cnt:.1f} barrier)" for n, w, q in zip(names, work, bar)) +
           f"; sum {(work.sum() + bar.sum()) / cnt:.1f} us")
+# inside workgroup 0's factorisation (first solve): after each panel's row solves, after its trailing update, after the
+# forward and after the backward substitution
+s3 = raw[128 * 256:]
+s3 = (s3[s3 > 0] - t0) * 0.01
+per = (6 * (K - 2)) // 6 * 2 + 2
+if len(s3) >= per and len(s2) >= 2:
+    first = s3[:per]
+    print("first solve from 'assembled': " + " ".join(f"{v - s2[0]:.2f}" for v in first))

@@ -22,11 +22,22 @@ s = s.replace('    unsigned int gen = 0;\n', '    unsigned int gen = 0;\n    int
 mark = '            const bool ok = bg_factor_solve(S, rhs, Tp, n);\n'
 assert s.count(mark) == 1, "the solve hook did not apply"
 s = s.replace(mark, '            BG_ST2();\n' + mark + '            BG_ST2();\n', 1)
+for mark, where in (("        __syncthreads();\n        // the block's own rows:", "before"),
+                    ("        __syncthreads();\n    }\n    bool ok = true;", "after_sync"),
+                    ("        if (i0 < n) r0 /= S[BG_TRI(i0, i0)];", "before"),
+                    ("        const bool finite =", "before")):
+    assert s.count(mark) == 1, "a factorisation hook did not apply: " + mark
+    if where == "before":
+        s = s.replace(mark, "        BG_ST3();\n" + mark, 1)
+    else:
+        s = s.replace(mark, "        __syncthreads();\n        BG_ST3();\n    }\n    bool ok = true;", 1)
 s = s.replace('#define BA_THREADS 256\n', '#define BA_THREADS 256\n__device__ unsigned long long* g_st = nullptr;\n'
               'extern "C" __attribute__((visibility("default"))) int slam_exp_set_ba_stamps(void* p) '
               '{ return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_st), &p, sizeof(p)); }\n'
               '#define BG_ST() do { if (tid == 0 && g_st && sidx < 200) g_st[blk * 256 + sidx] = wall_clock64(); sidx++; } while (0)\n'
-              '#define BG_ST2() do { if (tid == 0 && g_st && s2idx < 56) g_st[blk * 256 + 200 + s2idx] = wall_clock64(); s2idx++; } while (0)\n', 1)
+              '#define BG_ST2() do { if (tid == 0 && g_st && s2idx < 56) g_st[blk * 256 + 200 + s2idx] = wall_clock64(); s2idx++; } while (0)\n'
+              '__device__ int g_s3 = 0;\n'
+              '#define BG_ST3() do { if (threadIdx.x == 0 && g_st && g_s3 < 2048) g_st[128 * 256 + g_s3++] = wall_clock64(); } while (0)\n', 1)
 open(sys.argv[2], 'w').write(s)
 PY
 /opt/rocm/bin/hipcc $FLAGS -c "$TMP/ba_stamps.hip" -o "$TMP/ba_stamps.o"
