@@ -446,14 +446,16 @@ def test_one_launch_ba_refuses_bad_windows_before_launching(gpu_ctx):
 
 
 @pytest.mark.parametrize("K,L,delta,fixed,density", [(7, 300, 0.0, (0, 1), 0.6), (7, 1400, 1.0, (0, 1), 0.6), (3, 40, 1.5, (0,), 0.9),
-                                                       (17, 200, 0.0, (0,), 0.5), (5, 60, 0.0, (0, 1, 2, 3, 4), 0.8)])
+                                                       (17, 200, 0.0, (0,), 0.5), (5, 60, 0.0, (0, 1, 2, 3, 4), 0.8),
+                                                       (3, 4000, 0.0, (0,), 0.9)])
 def test_one_launch_ba_follows_the_oracle_trajectory(gpu_ctx, K, L, delta, fixed, density):
     """slam_ba_optimize_f64 (the whole window LM in one launch: linearisation, Schur complement, dense LDL^T solve in
     LDS, exp update, cost, accept / reject on the device) against oracle.ba_lm_np, the CPU loop over the C oracle's
     residuals and Jacobians: the same number of accepted steps, the same final cost (1e-9 relative), poses to 1e-8,
     points to 1e-7; and against the host-driven device form (slam_ba_reduce_f64 + numpy solve).  Cases: the reference's
     window of 7 keyframes with and without the Huber kernel, a tiny window, 16 free poses (the 96 x 96 system: the
-    largest the form takes), and a window whose every pose is fixed (nothing to solve: the state comes back unchanged)."""
+    largest the form takes), a window whose every pose is fixed (nothing to solve: the state comes back unchanged), and
+    three poses with 10 800 observations (six camera-block tasks cut into three slices each)."""
     from oracle import oracle
     from slamhip.ba import bundle_adjust_device, bundle_adjust_one_launch
 
