@@ -318,16 +318,19 @@ SLAM_API int slam_ba_backsub_f64(slam_ctx* ctx, int64_t L, const int32_t* d_pt_p
                                  const double* d_bl, const double* d_dp, double* d_dl);
 
 /* A whole window bundle adjustment in ONE launch: Levenberg-Marquardt with Schur complement as a persistent kernel of a
- * few dozen workgroups - the phases of slam_ba_reduce_f64 separated by grid barriers, the dense L D L^T solve of the
- * reduced camera system in LDS, the exp() update, the candidate's cost and the accept / reject decisions all on the
- * device; nothing crosses PCIe between trials (extension: backend.py:101-103 is an empty class over a Map of
+ * few dozen workgroups - the elimination of slam_ba_reduce_f64 as four phases separated by grid barriers (no per-observation
+ * records: every phase linearises the observations it touches again), the dense L D L^T solve of the reduced camera system
+ * in LDS, the exp() update, the candidate's cost and the accept / reject decisions all on the device; nothing crosses PCIe
+ * between trials (extension: backend.py:101-103 is an empty class over a Map of
  * NUM_ACTIVE_KEYFRAMES = 7 keyframes, backend.py:11).  For windows of at most SLAM_BA_LM_MAX_FREE moving poses (a 96 x 96
  * system), 64 poses and SLAM_BA_LM_MAX_OBS observations; larger ones use slam_ba_reduce_f64 / slam_ba_backsub_f64 with
  * a host solve.
  *   d_poses2  [2][K,12]  in: the state in the first half;  d_points2 [2][L,3] likewise.  out: the optimised state is in
  *             half `d_stats[6]` of both (the halves swap roles on every accepted step).
  *   index tables as slam_ba_reduce_f64 (obs_pose / obs_point [O], pt_ptr [L+1] / pt_obs [O], ps_ptr [K+1] / ps_obs [O]);
- *             a (pose, point) pair may be observed once; the (pose, point) -> observation table is built on the device.
+ *             a (pose, point) pair may be observed once; the (pose, point) -> observation table is built on the device.  A
+ *             pose or point index outside the window is counted (slam_index_errors) and ends the launch (status 1); the
+ *             four CSR arrays are trusted (slam_ba_optimize_host_f64 builds them itself).
  *   d_free_poses int32 [n_free], ascending: the poses that move (the others hold the gauge).
  *   d_work    scratch of slam_ba_optimize_workspace(K, L, O) bytes, 16-byte aligned.
  *   d_stats   double [8]: initial cost, final cost, accepted steps, trials, final lambda, status (0 = ok; all NaN until the

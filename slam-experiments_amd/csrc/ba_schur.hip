@@ -858,6 +858,15 @@ __device__ __forceinline__ void bg_load_row8(const bg_args& a, int base, int a1,
     for (int u = 0; u < 8; u++) { c.k[u] = a.obs_pose[o[u]]; c.m[u] = a.meas[o[u]]; }
 }
 
+// a grid barrier; an abandoned launch says so in its status word (the other seven stay NaN) and ends
+#define BG_SYNC_OR_QUIT()                                   \
+    do {                                                    \
+        if (!bg_grid_sync(c, G, gen)) {                     \
+            if (blk == 0 && tid == 0) a.stats[5] = 1.0;     \
+            return;                                         \
+        }                                                   \
+    } while (0)
+
 __global__ __launch_bounds__(BA_THREADS) void ba_lm_grid_kernel(const bg_args a) {
     __shared__ double S[BG_TRI(BG_MAXN, 0)];       // block 0: the reduced system, lower triangle packed by rows (37 KiB at 96 x 96)
     __shared__ double rhs[BG_MAXN];
@@ -884,7 +893,7 @@ __global__ __launch_bounds__(BA_THREADS) void ba_lm_grid_kernel(const bg_args a)
     // ---- phase 0: the (pose, point) -> observation table, on the device; an index outside the window is counted
     //      (slam_index_errors) and ends the launch: every later phase trusts the two index arrays -------------------------------
     for (long long i = (long long)blk * BA_THREADS + tid; i < (long long)K * L; i += (long long)G * BA_THREADS) a.lookup[i] = -1;
-    if (!bg_grid_sync(c, G, gen)) return;
+    BG_SYNC_OR_QUIT();
     for (int o = blk * BA_THREADS + tid; o < O; o += G * BA_THREADS) {
         const int k = a.obs_pose[o], l = a.obs_point[o];
         if ((unsigned)k >= (unsigned)K || (unsigned)l >= (unsigned)L) {
@@ -894,7 +903,7 @@ __global__ __launch_bounds__(BA_THREADS) void ba_lm_grid_kernel(const bg_args a)
             a.lookup[(size_t)k * L + l] = o;
         }
     }
-    if (!bg_grid_sync(c, G, gen)) return;
+    BG_SYNC_OR_QUIT();
 
     while (!done) {
         const double lam = lambda < 0.0 ? 1.0 : lambda;             // the very first pass only measures the diagonal
@@ -936,7 +945,7 @@ __global__ __launch_bounds__(BA_THREADS) void ba_lm_grid_kernel(const bg_args a)
             for (int i = 0; i < 3; i++) a.bl[(size_t)l * 3 + i] = b[i];
             a.hll[(size_t)l * 3] = h[0]; a.hll[(size_t)l * 3 + 1] = h[3]; a.hll[(size_t)l * 3 + 2] = h[5];
         }
-        if (!bg_grid_sync(c, G, gen)) return;
+        BG_SYNC_OR_QUIT();
         // ---- per pose: Hpp, bp, y, cost; per pair of free poses: W.  A task (a pose's, or a pair's first pose's, observation
         //      list) is cut into nsub slices, one workgroup each; the consumers add the slices up in slice order.  The very
         //      first pass only measures the diagonal and the cost: it runs the pose tasks alone --------------------------------
@@ -958,7 +967,7 @@ __global__ __launch_bounds__(BA_THREADS) void ba_lm_grid_kernel(const bg_args a)
                 __syncthreads();
             }
         }
-        if (!bg_grid_sync(c, G, gen)) return;
+        BG_SYNC_OR_QUIT();
 
         if (lambda < 0.0) {
             // initial damping: tau * the largest diagonal entry of the free poses' Hpp and of every Hll (every workgroup
@@ -1017,7 +1026,7 @@ __global__ __launch_bounds__(BA_THREADS) void ba_lm_grid_kernel(const bg_args a)
                 for (int i = tid; i < n; i += BA_THREADS) a.dp[(size_t)a.free_list[i / 6] * 6 + i % 6] = rhs[i];
             if (tid == 0) c->solved = s_solved;
         }
-        if (!bg_grid_sync(c, G, gen)) return;
+        BG_SYNC_OR_QUIT();
         if (!bg_load(&c->solved)) {                    // a factorisation that fails counts as a trial
             lambda = lam * ni; ni *= 2.0; trials++; trial++;
             if (trial >= 10 || !isfinite(lambda)) done = 1;
@@ -1104,7 +1113,7 @@ __global__ __launch_bounds__(BA_THREADS) void ba_lm_grid_kernel(const bg_args a)
             ba_block_sum<2>(acc, (double(*)[2])sw, out);
             if (tid == 0) { a.part[2 * blk] = out[0]; a.part[2 * blk + 1] = out[1]; }
         }
-        if (!bg_grid_sync(c, G, gen)) return;
+        BG_SYNC_OR_QUIT();
         // ---- verdict (replicated) ------------------------------------------------------------------------------------------------------
         {
             double scale = 1e-3, cc = 0.0;

@@ -501,3 +501,46 @@ def test_one_launch_ba_limits_are_reported(gpu_ctx):
     assert lib.slam_ba_optimize_f64(ctx.handle, 7, 1400, 6000, *args, buf.ptr, 5, FX, FY, CX, CY, 0.0, 5, buf.ptr, buf.ptr, buf.ptr, 4096, buf.ptr) == -1
     assert b"workspace" in lib.slam_last_error()
     buf.free()
+
+
+def test_one_launch_ba_ends_the_launch_on_an_index_outside_the_window(gpu_ctx):
+    """slam_ba_optimize_f64 on device arrays (no host-side checks in front of it): an observation whose pose or point index
+    lies outside the window is counted for slam_index_errors in the kernel's first phase and the launch ends there - status
+    1 in d_stats[5], the state untouched, nothing read out of bounds; the same window with the indices repaired runs."""
+    import ctypes
+
+    rng = np.random.default_rng(5)
+    K, L = 4, 60
+    T, X, op, ol, meas = _window(rng, K, L, 0.8)
+    O = len(op)
+    lib, ctx = gpu_ctx.lib, gpu_ctx
+
+    def run(op_, ol_):
+        pt_obs = np.argsort(np.clip(ol_, 0, L - 1), kind="stable").astype(np.int32)
+        ps_obs = np.argsort(np.clip(op_, 0, K - 1), kind="stable").astype(np.int32)
+        pt_ptr = np.zeros(L + 1, np.int32); pt_ptr[1:] = np.cumsum(np.bincount(np.clip(ol_, 0, L - 1), minlength=L))
+        ps_ptr = np.zeros(K + 1, np.int32); ps_ptr[1:] = np.cumsum(np.bincount(np.clip(op_, 0, K - 1), minlength=K))
+        free = np.arange(1, K, dtype=np.int32)
+        d = [ctx.upload(a) for a in (op_.astype(np.int32), ol_.astype(np.int32), meas, pt_ptr, pt_obs, ps_ptr, ps_obs, free)]
+        state_T = np.concatenate([T[:, :3, :4].reshape(-1), np.zeros(K * 12)])
+        state_X = np.concatenate([X.reshape(-1), np.zeros(L * 3)])
+        dT, dX = ctx.upload(state_T), ctx.upload(state_X)
+        need = ctypes.c_uint64(0)
+        assert lib.slam_ba_optimize_workspace(K, L, O, ctypes.byref(need)) == 0
+        dW, dS = ctx.malloc(need.value), ctx.malloc(64)
+        assert lib.slam_ba_optimize_f64(ctx.handle, K, L, O, *[b.ptr for b in d], len(free), FX, FY, CX, CY, 0.0, 3, dT.ptr, dX.ptr,
+                                        dW.ptr, need.value, dS.ptr) == 0
+        st = dS.download(np.float64, (8,))
+        return st, dT.download(np.float64, (2 * K * 12,)), state_T
+
+    cnt = ctypes.c_int64(0)
+    assert lib.slam_index_errors(ctx.handle, ctypes.byref(cnt)) == 0          # clear whatever earlier tests left
+    bad_op, bad_ol = op.copy(), ol.copy()
+    bad_op[3] = K; bad_op[10] = -1; bad_ol[17] = L + 5
+    st, Tout, Tin = run(bad_op, bad_ol)
+    assert st[5] == 1.0 and np.isnan(st[2])
+    assert np.array_equal(Tout[:K * 12], Tin[:K * 12])
+    assert lib.slam_index_errors(ctx.handle, ctypes.byref(cnt)) == 0 and cnt.value == 3
+    st, _, _ = run(op, ol)
+    assert st[5] == 0.0 and st[2] >= 1 and st[1] < st[0]
+    assert lib.slam_index_errors(ctx.handle, ctypes.byref(cnt)) == 0 and cnt.value == 0

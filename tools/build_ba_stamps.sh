@@ -14,7 +14,7 @@ OBJS=$(ls "$ROOT"/slam-experiments_amd/lib/obj/*.o | grep -v ba_schur)
 python3 - "$SRC/ba_schur.hip" "$TMP/ba_stamps.hip" <<'PY'
 import sys
 s = open(sys.argv[1]).read()
-bar = 'if (!bg_grid_sync(c, G, gen)) return;'
+bar = 'BG_SYNC_OR_QUIT();'
 n = s.count(bar)
 assert n >= 6, "the barrier hooks did not apply: the kernel source changed"
 s = s.replace(bar, 'BG_ST(); ' + bar + ' BG_ST();')
