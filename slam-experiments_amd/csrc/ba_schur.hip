@@ -34,12 +34,12 @@ struct ba_cam { double fx, fy, cx, cy; };
 //   [63..68] upper triangle of Jq^T w Jq (6)    [69..71] Jq^T w e (3)    [72] rho(e.e)
 #define BA_REC 73
 // The records are kept observation-major (73 consecutive doubles per observation).  Two field-major layouts - field f
-// of observation o at rec[f * O + o], and the same inside tiles of 64 observations - were measured with
-// tools/ba_phase_probe.py and were SLOWER, although they make a wave's loads contiguous: the pose and pair phases of the
-// one-launch form went from 20 to 48 us at the reference's window.  Behind a grid barrier every read comes from memory
-// and a phase is bound by what ONE compute unit can pull (about 30 GB/s here: ~17 ns per observation and CU in the
-// point, pose and pair phases alike); a thread that walks its own contiguous record keeps more of those reads in flight
-// than 46 separate streams do.  Hence the other remedy: more workgroups per phase (bg_shape).
+// of observation o at rec[f * O + o], and the same inside tiles of 64 observations - were measured while the one-launch
+// form at the end of this file still passed records from phase to phase (tools/ba_phase_probe.py) and were SLOWER,
+// although they make a wave's loads contiguous: its pose and pair phases went from 20 to 48 us at the reference's window;
+// a thread that walks its own contiguous record keeps more reads in flight than 46 separate streams do.  That form has
+// since dropped the records altogether (it linearises again wherever it needs a Jacobian); the per-phase kernels below,
+// which the host drives for windows beyond its limits, keep them.
 struct ba_rec_ref {
     double* base;
     __device__ __forceinline__ double& operator[](int f) const { return base[f]; }
