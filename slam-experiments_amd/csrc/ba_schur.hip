@@ -466,7 +466,7 @@ extern "C" int slam_ba_backsub_f64(slam_ctx* ctx, int64_t L, const int32_t* d_pt
 struct bg_ctl {
     unsigned int arrive; unsigned int pad0[31];   // the grid barrier: the ticket counter and the generation word the waiters poll
     unsigned int gen; unsigned int pad1[31];      // live in cache lines of their own
-    int abort, solved;                            // launch abandoned; did workgroup 0's factorisation succeed
+    int abort;                                    // launch abandoned
 };
 
 struct bg_args {
@@ -479,7 +479,7 @@ struct bg_args {
     // per pose and slice (slot k * nsub + s): [.*21] [.*6] [.*6] [.]; per pair of free poses and slice: [.*36]; bpc [K*6]:
     // the slices of bp added up (workgroup 0, with the solve), for the gain ratio's denominator
     double* Hpp; double* bp; double* ybl; double* costk; double* bpc; double* W;
-    double* dp; double* dl; double* part;                        // [K*6], [L*3], [nblocks][2] (gain-ratio denominator, candidate cost)
+    double* dp; double* dl; double* part;                        // [K*6 + 1] (the steps, then the factorisation's outcome), [L*3], [nblocks][2] (gain-ratio denominator, candidate cost)
     bg_ctl* ctl;
     double* stats;
     unsigned int* index_errors;
@@ -847,15 +847,17 @@ __device__ void bg_apply_update(const double* dx, const double* T, double* Tn) {
     }
 }
 
-// up to eight observations of a point's row, their poses and measurements, loaded level by level (entry -> observation ->
-// (pose, measurement)): indices clamped into the row, the surplus to be masked by the caller (see bg_pose)
-struct bg_row8 { int k[8]; double2 m[8]; };
-__device__ __forceinline__ void bg_load_row8(const bg_args& a, int base, int a1, bg_row8& c) {
-    int o[8];
-#pragma unroll
-    for (int u = 0; u < 8; u++) o[u] = a.pt_obs[min(base + u, a1 - 1)];
-#pragma unroll
-    for (int u = 0; u < 8; u++) { c.k[u] = a.obs_pose[o[u]]; c.m[u] = a.meas[o[u]]; }
+// sum over the four lanes of a quad (DPP quad_perm, no LDS): every lane gets (v0 + v1) + (v2 + v3) or its mirror image -
+// the same bits, addition being commutative.  All four lanes must be active.
+__device__ __forceinline__ double bg_quad_sum(double v) {
+    long long b = __double_as_longlong(v);
+    int lo = __builtin_amdgcn_update_dpp(0, (int)b, 0xB1, 0xF, 0xF, true);            // quad_perm [1,0,3,2]
+    int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0xB1, 0xF, 0xF, true);
+    v += __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+    b = __double_as_longlong(v);
+    lo = __builtin_amdgcn_update_dpp(0, (int)b, 0x4E, 0xF, 0xF, true);                // quad_perm [2,3,0,1]
+    hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x4E, 0xF, 0xF, true);
+    return v + __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
 // a grid barrier; an abandoned launch says so in its status word (the other seven stay NaN) and ends
@@ -874,6 +876,7 @@ __global__ __launch_bounds__(BA_THREADS) void ba_lm_grid_kernel(const bg_args a)
     __shared__ double sw[4][36];
     __shared__ double out[36];
     __shared__ int s_solved;
+    __shared__ int s_ps_ptr[65], s_free[SLAM_BA_LM_MAX_FREE];   // the poses' list heads and the free poses, read once
     __shared__ double sT[64 * 12];                 // the poses of the state, per workgroup (K <= 64)
     __shared__ double sTn[64 * 12];                // the candidate poses
     __shared__ double sdp[64 * 6];                 // and the pose steps they come from
@@ -886,7 +889,7 @@ __global__ __launch_bounds__(BA_THREADS) void ba_lm_grid_kernel(const bg_args a)
     unsigned int gen = 0;
     // The Levenberg-Marquardt state is REPLICATED: every thread of every workgroup holds it and updates it with the same
     // arithmetic on the same device-memory values (read behind a grid barrier), so no verdict has to be published and
-    // waited for - only the factorisation's outcome (workgroup 0's) travels through the control block.
+    // waited for - only the factorisation's outcome (workgroup 0's) travels, with the pose steps it produced.
     int cur = 0, accepted = 0, trials = 0, iter = 0, trial = 0, done = 0;
     double lambda = -1.0, ni = 2.0, cost = 0.0;      // lambda < 0: "not measured yet"
 
@@ -905,45 +908,55 @@ __global__ __launch_bounds__(BA_THREADS) void ba_lm_grid_kernel(const bg_args a)
     }
     BG_SYNC_OR_QUIT();
 
+    // The small tables every workgroup reads in every pass are read once, here.  The poses of the state live in LDS from
+    // here on: every workgroup computes the candidate poses anyway and takes them over when a step is accepted.
+    for (int i = tid; i <= K; i += BA_THREADS) s_ps_ptr[i] = a.ps_ptr[i];
+    for (int i = tid; i < nf; i += BA_THREADS) s_free[i] = a.free_list[i];
+    for (int i = tid; i < K * 12; i += BA_THREADS) sT[i] = a.T[i];
+    __syncthreads();
+
     while (!done) {
         const double lam = lambda < 0.0 ? 1.0 : lambda;             // the very first pass only measures the diagonal
-        const double* T = a.T + (size_t)cur * K * 12;
         const double* X = a.X + (size_t)cur * L * 3;
         double* Tn = a.T + (size_t)(1 - cur) * K * 12;
         double* Xn = a.X + (size_t)(1 - cur) * L * 3;
 
-        for (int i = tid; i < K * 12; i += BA_THREADS) sT[i] = T[i];
-        __syncthreads();
         // ---- points: Hll, bl over the point's observations, E = (Hll + lambda I)^-1 ---------------------------------------------
-        for (int l = blk * perL + tid; l < min(L, (blk + 1) * perL); l += BA_THREADS) {
+        // (FOUR lanes per point, each taking every fourth observation of the point's row, their partial sums added across
+        // the quad: a thread's observations are a serial chain - loads, then ~40 dependent f64 operations each - and a
+        // point seen by all the keyframes made that chain the phase)
+        for (int qd = tid; qd < 4 * perL; qd += BA_THREADS) {
+            const int l = blk * perL + (qd >> 2), sub = qd & 3;
+            if (l >= min(L, (blk + 1) * perL)) continue;                 // (a whole quad at a time)
             const int a0 = a.pt_ptr[l], a1 = a.pt_ptr[l + 1];
             double x[3], h[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
 #pragma unroll
             for (int cI = 0; cI < 3; cI++) x[cI] = X[(size_t)l * 3 + cI];
-            for (int base = a0; base < a1; base += 8) {
-                bg_row8 row;
-                bg_load_row8(a, base, a1, row);
+            for (int i = a0 + sub; i < a1; i += 4) {
+                const int o = a.pt_obs[i];
+                ba_lin q;
+                ba_linearise(sT + (size_t)a.obs_pose[o] * 12, x, a.meas[o], a.cam, a.delta, q);
+                int t = 0;
 #pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    if (base + u >= a1) break;
-                    ba_lin q;
-                    ba_linearise(sT + (size_t)row.k[u] * 12, x, row.m[u], a.cam, a.delta, q);
-                    int t = 0;
+                for (int r = 0; r < 3; r++)
 #pragma unroll
-                    for (int r = 0; r < 3; r++)
+                    for (int cI = r; cI < 3; cI++) h[t++] += q.w * (q.jq[0][r] * q.jq[0][cI] + q.jq[1][r] * q.jq[1][cI]);
 #pragma unroll
-                        for (int cI = r; cI < 3; cI++) h[t++] += q.w * (q.jq[0][r] * q.jq[0][cI] + q.jq[1][r] * q.jq[1][cI]);
-#pragma unroll
-                    for (int r = 0; r < 3; r++) b[r] += q.w * (q.jq[0][r] * q.e0 + q.jq[1][r] * q.e1);
-                }
+                for (int r = 0; r < 3; r++) b[r] += q.w * (q.jq[0][r] * q.e0 + q.jq[1][r] * q.e1);
             }
+#pragma unroll
+            for (int i = 0; i < 6; i++) h[i] = bg_quad_sum(h[i]);
+#pragma unroll
+            for (int i = 0; i < 3; i++) b[i] = bg_quad_sum(b[i]);
             double e[9];
             ba_damped_inverse(h, lam, a1 > a0, e);
+            if (sub == 0) {
 #pragma unroll
-            for (int i = 0; i < 9; i++) a.E[(size_t)l * 9 + i] = e[i];
+                for (int i = 0; i < 9; i++) a.E[(size_t)l * 9 + i] = e[i];
 #pragma unroll
-            for (int i = 0; i < 3; i++) a.bl[(size_t)l * 3 + i] = b[i];
-            a.hll[(size_t)l * 3] = h[0]; a.hll[(size_t)l * 3 + 1] = h[3]; a.hll[(size_t)l * 3 + 2] = h[5];
+                for (int i = 0; i < 3; i++) a.bl[(size_t)l * 3 + i] = b[i];
+                a.hll[(size_t)l * 3] = h[0]; a.hll[(size_t)l * 3 + 1] = h[3]; a.hll[(size_t)l * 3 + 2] = h[5];
+            }
         }
         BG_SYNC_OR_QUIT();
         // ---- per pose: Hpp, bp, y, cost; per pair of free poses: W.  A task (a pose's, or a pair's first pose's, observation
@@ -958,9 +971,9 @@ __global__ __launch_bounds__(BA_THREADS) void ba_lm_grid_kernel(const bg_args a)
                 else {
                     int pi = task - K, f1 = 0;
                     while (pi >= nf - f1) { pi -= nf - f1; f1++; }
-                    k1 = a.free_list[f1]; k2 = a.free_list[f1 + pi];
+                    k1 = s_free[f1]; k2 = s_free[f1 + pi];
                 }
-                const int p0 = a.ps_ptr[k1], p1 = a.ps_ptr[k1 + 1], len = (p1 - p0 + nsub - 1) / nsub;
+                const int p0 = s_ps_ptr[k1], p1 = s_ps_ptr[k1 + 1], len = (p1 - p0 + nsub - 1) / nsub;
                 const int begin = min(p1, p0 + sl * len), end = min(p1, begin + len);
                 if (task < K) bg_pose(a, X, sT, k1, begin, end, sl * K + k1, (double(*)[34])sw, out);
                 else bg_pair(a, X, sT, k1, k2, begin, end, sl * npair + (task - K), sw, out);
@@ -976,7 +989,7 @@ __global__ __launch_bounds__(BA_THREADS) void ba_lm_grid_kernel(const bg_args a)
             for (int i = tid; i < L * 3; i += BA_THREADS) v = fmax(v, a.hll[i]);
             for (int i = tid; i < nf * 6; i += BA_THREADS) {
                 const int d = i % 6;
-                v = fmax(v, bg_slices(a.Hpp + (size_t)a.free_list[i / 6] * 21 + d * 6 - d * (d - 1) / 2, nsub, K * 21));   // diagonal entry d of the packed upper triangle
+                v = fmax(v, bg_slices(a.Hpp + (size_t)s_free[i / 6] * 21 + d * 6 - d * (d - 1) / 2, nsub, K * 21));   // diagonal entry d of the packed upper triangle
             }
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
@@ -1004,7 +1017,7 @@ __global__ __launch_bounds__(BA_THREADS) void ba_lm_grid_kernel(const bg_args a)
                 double v;
                 if (fa == fb) {
                     const int tri = jj * 6 - jj * (jj - 1) / 2 + (ii - jj);        // jj <= ii: index in the packed upper triangle of Hpp
-                    v = bg_slices(a.Hpp + (size_t)a.free_list[fa] * 21 + tri, nsub, K * 21) + (ii == jj ? lam : 0.0) -
+                    v = bg_slices(a.Hpp + (size_t)s_free[fa] * 21 + tri, nsub, K * 21) + (ii == jj ? lam : 0.0) -
                         bg_slices(a.W + (size_t)pidx * 36 + ii * 6 + jj, nsub, npair * 36);
                 } else {
                     v = -bg_slices(a.W + (size_t)pidx * 36 + jj * 6 + ii, nsub, npair * 36);   // fa > fb: the transpose of W[kb, ka]
@@ -1013,21 +1026,28 @@ __global__ __launch_bounds__(BA_THREADS) void ba_lm_grid_kernel(const bg_args a)
             }
             for (int i = tid; i < K * 6; i += BA_THREADS) a.bpc[i] = bg_slices(a.bp + i, nsub, K * 6);
             for (int i = tid; i < n; i += BA_THREADS) {
-                const size_t e = (size_t)a.free_list[i / 6] * 6 + i % 6;
+                const size_t e = (size_t)s_free[i / 6] * 6 + i % 6;
                 rhs[i] = -bg_slices(a.bp + e, nsub, K * 6) + bg_slices(a.ybl + e, nsub, K * 6);
             }
             __syncthreads();
             const bool ok = bg_factor_solve(S, rhs, Tp, n);
             if (tid == 0) s_solved = ok ? 1 : 0;
             __syncthreads();
+            // the steps of all K poses (zero for the fixed ones), then the factorisation's outcome
             for (int i = tid; i < K * 6; i += BA_THREADS) a.dp[i] = 0.0;
             __syncthreads();
             if (s_solved)
-                for (int i = tid; i < n; i += BA_THREADS) a.dp[(size_t)a.free_list[i / 6] * 6 + i % 6] = rhs[i];
-            if (tid == 0) c->solved = s_solved;
+                for (int i = tid; i < n; i += BA_THREADS) a.dp[(size_t)s_free[i / 6] * 6 + i % 6] = rhs[i];
+            if (tid == 0) a.dp[K * 6] = (double)s_solved;
         }
         BG_SYNC_OR_QUIT();
-        if (!bg_load(&c->solved)) {                    // a factorisation that fails counts as a trial
+        for (int i = tid; i <= K * 6; i += BA_THREADS) {
+            const double v = a.dp[i];
+            if (i < K * 6) sdp[i] = v;
+            else s_solved = v != 0.0;
+        }
+        __syncthreads();
+        if (!s_solved) {                               // a factorisation that fails counts as a trial
             lambda = lam * ni; ni *= 2.0; trials++; trial++;
             if (trial >= 10 || !isfinite(lambda)) done = 1;
             continue;
@@ -1037,73 +1057,63 @@ __global__ __launch_bounds__(BA_THREADS) void ba_lm_grid_kernel(const bg_args a)
         //      share of the gain ratio's denominator, and the candidate's robust cost over the point's observations (every
         //      workgroup keeps the K candidate poses in LDS; workgroup 0 also stores them) --------------------------------------
         {
-            for (int i = tid; i < K * 6; i += BA_THREADS) sdp[i] = a.dp[i];
-            __syncthreads();
             for (int k = tid; k < K; k += BA_THREADS) {
-                bg_apply_update(sdp + (size_t)k * 6, T + (size_t)k * 12, sTn + (size_t)k * 12);
+                bg_apply_update(sdp + (size_t)k * 6, sT + (size_t)k * 12, sTn + (size_t)k * 12);
                 if (blk == 0)
                     for (int x = 0; x < 12; x++) Tn[(size_t)k * 12 + x] = sTn[(size_t)k * 12 + x];
             }
             __syncthreads();
             double sc = 0.0, cc = 0.0;
-            for (int l = blk * perL + tid; l < min(L, (blk + 1) * perL); l += BA_THREADS) {
+            for (int qd = tid; qd < 4 * perL; qd += BA_THREADS) {    // four lanes per point, as in the point phase
+                const int l = blk * perL + (qd >> 2), sub = qd & 3;
+                if (l >= min(L, (blk + 1) * perL)) continue;
                 // dl = E (-bl - sum_{o of l} Hpl_o^T dp_pose(o)) as ba_backsub_body has it, Hpl linearised again, the pose steps from LDS
                 const int a0 = a.pt_ptr[l], a1 = a.pt_ptr[l + 1];
-                double t[3], bl3[3];
+                double t[3] = {0.0, 0.0, 0.0}, bl3[3], x0[3];
 #pragma unroll
-                for (int x = 0; x < 3; x++) { bl3[x] = a.bl[(size_t)l * 3 + x]; t[x] = -bl3[x]; }
-                double x0[3];
+                for (int x = 0; x < 3; x++) { bl3[x] = a.bl[(size_t)l * 3 + x]; x0[x] = X[(size_t)l * 3 + x]; }
+                for (int i = a0 + sub; i < a1; i += 4) {
+                    const int o = a.pt_obs[i], k = a.obs_pose[o];
+                    ba_lin q;
+                    ba_linearise(sT + (size_t)k * 12, x0, a.meas[o], a.cam, a.delta, q);
+                    double h[6][3];
+                    bg_hpl(q, h);
+                    const double* d = sdp + (size_t)k * 6;
 #pragma unroll
-                for (int cI = 0; cI < 3; cI++) x0[cI] = X[(size_t)l * 3 + cI];
-                bg_row8 first = {};                             // the row's first eight observations serve both loops
-                if (a1 > a0) bg_load_row8(a, a0, a1, first);
-                for (int base = a0; base < a1; base += 8) {
-                    bg_row8 row = first;
-                    if (base > a0) bg_load_row8(a, base, a1, row);
+                    for (int cI = 0; cI < 3; cI++)
 #pragma unroll
-                    for (int u = 0; u < 8; u++) {
-                        if (base + u >= a1) break;
-                        ba_lin q;
-                        ba_linearise(sT + (size_t)row.k[u] * 12, x0, row.m[u], a.cam, a.delta, q);
-                        double h[6][3];
-                        bg_hpl(q, h);
-                        const double* d = sdp + (size_t)row.k[u] * 6;
-#pragma unroll
-                        for (int cI = 0; cI < 3; cI++)
-#pragma unroll
-                            for (int aI = 0; aI < 6; aI++) t[cI] -= h[aI][cI] * d[aI];
-                    }
+                        for (int aI = 0; aI < 6; aI++) t[cI] -= h[aI][cI] * d[aI];
                 }
+#pragma unroll
+                for (int x = 0; x < 3; x++) t[x] = bg_quad_sum(t[x]) - bl3[x];
                 const double* e = a.E + (size_t)l * 9;
                 double p[3];
 #pragma unroll
                 for (int x = 0; x < 3; x++) {
                     const double d = a1 > a0 ? e[x * 3] * t[0] + e[x * 3 + 1] * t[1] + e[x * 3 + 2] * t[2] : 0.0;
-                    a.dl[(size_t)l * 3 + x] = d;
                     p[x] = x0[x] + d;
-                    Xn[(size_t)l * 3 + x] = p[x];
-                    sc += d * (lam * d - bl3[x]);
-                }
-                for (int base = a0; base < a1; base += 8) {
-                    bg_row8 row = first;
-                    if (base > a0) bg_load_row8(a, base, a1, row);
-#pragma unroll
-                    for (int u = 0; u < 8; u++) {
-                        if (base + u >= a1) break;
-                        const double* P = sTn + (size_t)row.k[u] * 12;
-                        const double Xc = P[0] * p[0] + P[1] * p[1] + P[2] * p[2] + P[3];
-                        const double Yc = P[4] * p[0] + P[5] * p[1] + P[6] * p[2] + P[7];
-                        const double Zc = P[8] * p[0] + P[9] * p[1] + P[10] * p[2] + P[11];
-                        const double e0 = row.m[u].x - (a.cam.fx * Xc + a.cam.cx * Zc) / Zc;
-                        const double e1 = row.m[u].y - (a.cam.fy * Yc + a.cam.cy * Zc) / Zc;
-                        const double c2 = e0 * e0 + e1 * e1;
-                        double rho = c2;
-                        if (a.delta > 0.0) {
-                            const double en = sqrt(c2);
-                            if (en > a.delta) rho = 2.0 * a.delta * en - a.delta * a.delta;
-                        }
-                        cc += rho;
+                    if (sub == 0) {
+                        a.dl[(size_t)l * 3 + x] = d;
+                        Xn[(size_t)l * 3 + x] = p[x];
+                        sc += d * (lam * d - bl3[x]);
                     }
+                }
+                for (int i = a0 + sub; i < a1; i += 4) {
+                    const int o = a.pt_obs[i];
+                    const double* P = sTn + (size_t)a.obs_pose[o] * 12;
+                    const double Xc = P[0] * p[0] + P[1] * p[1] + P[2] * p[2] + P[3];
+                    const double Yc = P[4] * p[0] + P[5] * p[1] + P[6] * p[2] + P[7];
+                    const double Zc = P[8] * p[0] + P[9] * p[1] + P[10] * p[2] + P[11];
+                    const double2 m = a.meas[o];
+                    const double e0 = m.x - (a.cam.fx * Xc + a.cam.cx * Zc) / Zc;
+                    const double e1 = m.y - (a.cam.fy * Yc + a.cam.cy * Zc) / Zc;
+                    const double c2 = e0 * e0 + e1 * e1;
+                    double rho = c2;
+                    if (a.delta > 0.0) {
+                        const double en = sqrt(c2);
+                        if (en > a.delta) rho = 2.0 * a.delta * en - a.delta * a.delta;
+                    }
+                    cc += rho;
                 }
             }
             if (blk == 0)
@@ -1122,6 +1132,7 @@ __global__ __launch_bounds__(BA_THREADS) void ba_lm_grid_kernel(const bg_args a)
             trials++;
             if (rho > 0.0 && isfinite(cc)) {
                 cur = 1 - cur;                             // the candidate buffers become the state
+                for (int i = tid; i < K * 12; i += BA_THREADS) sT[i] = sTn[i];
                 cost = cc;
                 const double g = 2.0 * rho - 1.0;
                 lambda = lam * fmax(1.0 / 3.0, fmin(1.0 - g * g * g, 2.0 / 3.0));
@@ -1134,6 +1145,7 @@ __global__ __launch_bounds__(BA_THREADS) void ba_lm_grid_kernel(const bg_args a)
                 trial++;
                 if (trial >= 10 || !isfinite(lambda)) done = 1;   // an iteration without an accepted step ends the run
             }
+            __syncthreads();
         }
     }
     if (blk == 0 && tid == 0) {
@@ -1177,7 +1189,7 @@ extern "C" int slam_ba_optimize_workspace(int64_t K, int64_t L, int64_t O, uint6
     *bytes = bg_round16(sizeof(bg_ctl)) + bg_round16((uint64_t)K * L * 4) +
              bg_round16((uint64_t)L * 72) + 2 * bg_round16((uint64_t)L * 24) + bg_round16(ks * 168) + 2 * bg_round16(ks * 48) +
              bg_round16(ks * 8) + bg_round16((uint64_t)K * 48) + bg_round16((uint64_t)BG_MAX_PAIRS * BG_MAX_SLICES * 288) +
-             bg_round16((uint64_t)K * 48) + bg_round16((uint64_t)L * 24) + bg_round16(2 * BG_MAX_BLOCKS * 8);
+             bg_round16((uint64_t)(K * 6 + 1) * 8) + bg_round16((uint64_t)L * 24) + bg_round16(2 * BG_MAX_BLOCKS * 8);
     return SLAM_OK;
 }
 
@@ -1216,7 +1228,7 @@ extern "C" int slam_ba_optimize_f64(slam_ctx* ctx, int64_t K, int64_t L, int64_t
     a.Hpp = (double*)take(ks * 168); a.bp = (double*)take(ks * 48); a.ybl = (double*)take(ks * 48);
     a.costk = (double*)take(ks * 8); a.bpc = (double*)take((uint64_t)K * 48);
     a.W = (double*)take((uint64_t)BG_MAX_PAIRS * BG_MAX_SLICES * 288);
-    a.dp = (double*)take((uint64_t)K * 48); a.dl = (double*)take((uint64_t)L * 24);
+    a.dp = (double*)take((uint64_t)(K * 6 + 1) * 8); a.dl = (double*)take((uint64_t)L * 24);
     a.part = (double*)take(2 * BG_MAX_BLOCKS * 8);
     a.stats = d_stats;
     a.index_errors = slam_index_error_counter(ctx);
