@@ -449,11 +449,11 @@ extern "C" int slam_ba_backsub_f64(slam_ctx* ctx, int64_t L, const int32_t* d_pt
 // of up to 46 of a 584-byte record, and no phase that writes them).  Behind a grid barrier every read comes from memory,
 // and the record traffic was what the phases cost (~17 ns per observation and compute unit, tools/ba_phase_probe.py); the
 // arithmetic is free beside it.  Four barriers per trial:
-//   points         one thread per point: Hll, bl over its observations, E = (Hll + lambda I)^-1
+//   points         four lanes per point: Hll, bl over its observations, E = (Hll + lambda I)^-1
 //   camera blocks  a workgroup per slice of a pose's observation list: Hpp, bp, y = sum Y bl, cost; and per slice of a pair
 //                  of free poses: W = sum Y_(k1,l) Hpl_(k2,l)^T, both observations linearised on the spot
 //   solve          workgroup 0: the reduced system from the slices, L D L^T, the pose steps
-//   step           one thread per point: dl by back-substitution, the candidate point, the candidate's robust cost
+//   step           four lanes per point: dl by back-substitution, the candidate point, the candidate's robust cost
 //
 // The grid barrier is the counter hand-off of cdna_hip_programming.md G16: every wave drains its stores, the
 // workgroup's barrier, then ONE lane does an agent-scope release, takes a ticket, and either opens the next generation
@@ -1053,7 +1053,7 @@ __global__ __launch_bounds__(BA_THREADS) void ba_lm_grid_kernel(const bg_args a)
             continue;
         }
 
-        // ---- the step and its verdict's ingredients, one thread per point: dl by back-substitution, the candidate point, its
+        // ---- the step and its verdict's ingredients, four lanes per point: dl by back-substitution, the candidate point, its
         //      share of the gain ratio's denominator, and the candidate's robust cost over the point's observations (every
         //      workgroup keeps the K candidate poses in LDS; workgroup 0 also stores them) --------------------------------------
         {
