@@ -486,6 +486,9 @@ struct bg_args {
     ba_cam cam; double delta;
 };
 
+#define BG_MAX_BLOCKS 128
+#define BG_MAX_SLICES 8
+#define BG_MAX_PAIRS (SLAM_BA_LM_MAX_FREE * (SLAM_BA_LM_MAX_FREE + 1) / 2)
 #define BG_TRI(i, j) ((i) * ((i) + 1) / 2 + (j))   // packed lower triangle, j <= i
 #define BG_MAXN (SLAM_BA_LM_MAX_FREE * 6)
 
@@ -650,8 +653,20 @@ __device__ __forceinline__ void bg_pair(const bg_args& a, const double* __restri
 
 // sum of the nsub slices of one entry, in slice order (stride = entries per slice block)
 __device__ __forceinline__ double bg_slices(const double* __restrict__ p, int nsub, int stride) {
-    double v = p[0];
-    for (int s = 1; s < nsub; s++) v += p[(size_t)s * stride];
+    // (every slice's load is issued before the first is added: one memory latency for the entry, not one per slice; nsub is
+    // the same in every thread, so the two loops end on scalar branches)
+    double q[BG_MAX_SLICES];
+#pragma unroll
+    for (int s = 0; s < BG_MAX_SLICES; s++) {
+        if (s >= nsub) break;
+        q[s] = p[(size_t)s * stride];
+    }
+    double v = q[0];
+#pragma unroll
+    for (int s = 1; s < BG_MAX_SLICES; s++) {
+        if (s >= nsub) break;
+        v += q[s];
+    }
     return v;
 }
 
@@ -1126,8 +1141,12 @@ __global__ __launch_bounds__(BA_THREADS) void ba_lm_grid_kernel(const bg_args a)
         BG_SYNC_OR_QUIT();
         // ---- verdict (replicated) ------------------------------------------------------------------------------------------------------
         {
-            double scale = 1e-3, cc = 0.0;
-            for (int b = 0; b < G; b++) { scale += a.part[2 * b]; cc += a.part[2 * b + 1]; }
+            // (the workgroups' partial sums are added by a block-wide reduction, the same one in every workgroup: a loop over
+            // them in every thread is a chain of G dependent loads and additions - 9 us of a trial at 121 workgroups)
+            double pr[2] = {0.0, 0.0};
+            for (int b = tid; b < G; b += BA_THREADS) { pr[0] += a.part[2 * b]; pr[1] += a.part[2 * b + 1]; }
+            ba_block_sum<2>(pr, (double(*)[2])sw, out);
+            const double scale = 1e-3 + out[0], cc = out[1];
             const double rho = (cost - cc) / scale;
             trials++;
             if (rho > 0.0 && isfinite(cc)) {
@@ -1161,17 +1180,14 @@ __global__ __launch_bounds__(BA_THREADS) void ba_lm_grid_kernel(const bg_args a)
 
 static inline uint64_t bg_round16(uint64_t b) { return (b + 15) / 16 * 16; }
 
-#define BG_MAX_BLOCKS 128
-#define BG_MAX_SLICES 8
-#define BG_MAX_PAIRS (SLAM_BA_LM_MAX_FREE * (SLAM_BA_LM_MAX_FREE + 1) / 2)
 
 // Number of workgroups of the persistent launch, and the slices a pose / pair task is cut into.  Measured at the
 // reference's window (7 keyframes, 5792 observations, 22 tasks; tools/ba_phase_probe.py, us per accepted step incl. its
-// four barriers): 22 workgroups 59.4, 46 (two slices per task) 62.2, 61 65, 91 73, 121 80 - the camera-block phase shrinks
-// with the slices (15.5 -> 13 -> 11 us), but the point phase grows with the number of workgroups (6.6 -> 9 -> 16 us: each
-// re-reads the poses and the lists' heads behind every barrier) and workgroup 0 adds the slices up before it can solve.
-// Hence one workgroup per task, more only when the lists are long (about 512 observations per workgroup), at most 128
-// (half the device: all of them must be resident at once), and as many slices as that width gives a workgroup each (<= 8).
+// four barriers): 22 workgroups 51.2, 44 (two slices per task) 51.7, 66 53.3, 88 54.0 - the camera-block phase shrinks
+// with the slices (14.8 -> 12.7 -> 12.0 us), but workgroup 0 adds the slices up before it can solve (17 -> 18 -> 20 us) and
+// every barrier grows with the launch (2.3 -> 3.0 us).  Hence one workgroup per task, more only when the lists are long
+// (about 512 observations per workgroup), at most 128 (half the device: all of them must be resident at once), and as
+// many slices as that width gives a workgroup each (<= 8).
 static void bg_shape(int64_t K, int64_t O, int64_t n_free, int* blocks, int* slices) {
     const int64_t ntask = K + n_free * (n_free + 1) / 2;
     int64_t want = (O + 511) / 512;
