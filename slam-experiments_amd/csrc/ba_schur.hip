@@ -475,7 +475,7 @@ struct bg_args {
     const int* pt_ptr; const int* pt_obs; const int* ps_ptr; const int* ps_obs; const int* free_list;
     int* lookup;
     double* T; double* X;                                        // [2][K*12], [2][L*3]
-    double* E; double* bl; double* hll;                          // [L*9], [L*3], [L*3]
+    double* E; double* bl;                                       // [L*9], [L*3]
     // per pose and slice (slot k * nsub + s): [.*21] [.*6] [.*6] [.]; per pair of free poses and slice: [.*36]; bpc [K*6]:
     // the slices of bp added up (workgroup 0, with the solve), for the gain ratio's denominator
     double* Hpp; double* bp; double* ybl; double* costk; double* bpc; double* W;
@@ -940,6 +940,7 @@ __global__ __launch_bounds__(BA_THREADS) void ba_lm_grid_kernel(const bg_args a)
         // (FOUR lanes per point, each taking every fourth observation of the point's row, their partial sums added across
         // the quad: a thread's observations are a serial chain - loads, then ~40 dependent f64 operations each - and a
         // point seen by all the keyframes made that chain the phase)
+        double hmax = 0.0;                                           // the largest diagonal entry of this thread's points' Hll
         for (int qd = tid; qd < 4 * perL; qd += BA_THREADS) {
             const int l = blk * perL + (qd >> 2), sub = qd & 3;
             if (l >= min(L, (blk + 1) * perL)) continue;                 // (a whole quad at a time)
@@ -970,8 +971,16 @@ __global__ __launch_bounds__(BA_THREADS) void ba_lm_grid_kernel(const bg_args a)
                 for (int i = 0; i < 9; i++) a.E[(size_t)l * 9 + i] = e[i];
 #pragma unroll
                 for (int i = 0; i < 3; i++) a.bl[(size_t)l * 3 + i] = b[i];
-                a.hll[(size_t)l * 3] = h[0]; a.hll[(size_t)l * 3 + 1] = h[3]; a.hll[(size_t)l * 3 + 2] = h[5];
+                hmax = fmax(hmax, fmax(h[0], fmax(h[3], h[5])));
             }
+        }
+        if (lambda < 0.0) {                                          // the first pass measures the diagonal: this workgroup's share
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) hmax = fmax(hmax, __shfl_xor(hmax, off, 64));
+            __syncthreads();
+            if (lane == 0) sw[wave][0] = hmax;
+            __syncthreads();
+            if (tid == 0) a.part[blk] = fmax(fmax(sw[0][0], sw[1][0]), fmax(sw[2][0], sw[3][0]));
         }
         BG_SYNC_OR_QUIT();
         // ---- per pose: Hpp, bp, y, cost; per pair of free poses: W.  A task (a pose's, or a pair's first pose's, observation
@@ -1000,8 +1009,11 @@ __global__ __launch_bounds__(BA_THREADS) void ba_lm_grid_kernel(const bg_args a)
         if (lambda < 0.0) {
             // initial damping: tau * the largest diagonal entry of the free poses' Hpp and of every Hll (every workgroup
             // computes it for itself: a maximum does not depend on the order)
+            // (the points' share comes as one maximum per workgroup from the point phase, and the poses' costs are added by a
+            // block-wide reduction: a loop over 3 L diagonal entries, or over the K costs, in every thread is a chain of
+            // dependent loads at the head of the launch)
             double v = 0.0;
-            for (int i = tid; i < L * 3; i += BA_THREADS) v = fmax(v, a.hll[i]);
+            for (int i = tid; i < G; i += BA_THREADS) v = fmax(v, a.part[i]);
             for (int i = tid; i < nf * 6; i += BA_THREADS) {
                 const int d = i % 6;
                 v = fmax(v, bg_slices(a.Hpp + (size_t)s_free[i / 6] * 21 + d * 6 - d * (d - 1) / 2, nsub, K * 21));   // diagonal entry d of the packed upper triangle
@@ -1012,8 +1024,10 @@ __global__ __launch_bounds__(BA_THREADS) void ba_lm_grid_kernel(const bg_args a)
             if (lane == 0) sw[wave][0] = v;
             __syncthreads();
             lambda = 1e-5 * fmax(fmax(fmax(sw[0][0], sw[1][0]), fmax(sw[2][0], sw[3][0])), 1e-12);
-            cost = 0.0;
-            for (int k = 0; k < K; k++) cost += bg_slices(a.costk + k, nsub, K);
+            double pc[1] = {0.0};
+            for (int k = tid; k < K; k += BA_THREADS) pc[0] += bg_slices(a.costk + k, nsub, K);
+            ba_block_sum<1>(pc, (double(*)[1])sw, out);
+            cost = out[0];
             if (blk == 0 && tid == 0) a.stats[0] = cost;
             if (a.iterations <= 0 || nf == 0) done = 1;
             __syncthreads();
@@ -1203,7 +1217,7 @@ extern "C" int slam_ba_optimize_workspace(int64_t K, int64_t L, int64_t O, uint6
     SLAM_REQUIRE(K >= 1 && K <= 64 && L >= 1 && L <= (1 << 24) && O >= 0 && O <= SLAM_BA_LM_MAX_OBS, "bad sizes");
     const uint64_t ks = (uint64_t)K * BG_MAX_SLICES;
     *bytes = bg_round16(sizeof(bg_ctl)) + bg_round16((uint64_t)K * L * 4) +
-             bg_round16((uint64_t)L * 72) + 2 * bg_round16((uint64_t)L * 24) + bg_round16(ks * 168) + 2 * bg_round16(ks * 48) +
+             bg_round16((uint64_t)L * 72) + bg_round16((uint64_t)L * 24) + bg_round16(ks * 168) + 2 * bg_round16(ks * 48) +
              bg_round16(ks * 8) + bg_round16((uint64_t)K * 48) + bg_round16((uint64_t)BG_MAX_PAIRS * BG_MAX_SLICES * 288) +
              bg_round16((uint64_t)(K * 6 + 1) * 8) + bg_round16((uint64_t)L * 24) + bg_round16(2 * BG_MAX_BLOCKS * 8);
     return SLAM_OK;
@@ -1239,13 +1253,14 @@ extern "C" int slam_ba_optimize_f64(slam_ctx* ctx, int64_t K, int64_t L, int64_t
     auto take = [&](uint64_t bytes) { char* p = w; w += bg_round16(bytes); return p; };
     a.ctl = (bg_ctl*)take(sizeof(bg_ctl));
     a.lookup = (int*)take((uint64_t)K * L * 4);
-    a.E = (double*)take((uint64_t)L * 72); a.bl = (double*)take((uint64_t)L * 24); a.hll = (double*)take((uint64_t)L * 24);
+    a.E = (double*)take((uint64_t)L * 72); a.bl = (double*)take((uint64_t)L * 24);
     const uint64_t ks = (uint64_t)K * BG_MAX_SLICES;
     a.Hpp = (double*)take(ks * 168); a.bp = (double*)take(ks * 48); a.ybl = (double*)take(ks * 48);
     a.costk = (double*)take(ks * 8); a.bpc = (double*)take((uint64_t)K * 48);
     a.W = (double*)take((uint64_t)BG_MAX_PAIRS * BG_MAX_SLICES * 288);
     a.dp = (double*)take((uint64_t)(K * 6 + 1) * 8); a.dl = (double*)take((uint64_t)L * 24);
     a.part = (double*)take(2 * BG_MAX_BLOCKS * 8);
+    SLAM_REQUIRE((uint64_t)(w - (char*)d_work) <= need, "slam_ba_optimize_f64: the workspace layout outgrew slam_ba_optimize_workspace");
     a.stats = d_stats;
     a.index_errors = slam_index_error_counter(ctx);
     a.cam = {fx, fy, cx, cy};
