@@ -338,7 +338,10 @@ SLAM_API int slam_ba_backsub_f64(slam_ctx* ctx, int64_t L, const int32_t* d_pt_p
  * Schedule: lambda0 = 1e-5 max diag(H of the free poses and of the points); `iterations` iterations of up to 10 trials;
  * rho = (cost - cost_new) / (dx.(lambda dx - b) + 1e-3); accepted: lambda *= max(1/3, min(1 - (2 rho - 1)^3, 2/3));
  * rejected (or a factorisation that fails): lambda *= ni, ni *= 2.  Every sum is formed in a fixed order: two runs
- * give identical bits.  Asynchronous on the ctx stream. */
+ * give identical bits.  Asynchronous on the ctx stream.  The launch holds one compute unit per workgroup (at most 128, see
+ * d_stats[7]) from start to end and needs all of them resident at once: launches of other contexts run beside it while
+ * their workgroups fit as well (two of the largest do); one that cannot get its workgroups resident gives up after a
+ * bounded wait and reports status 1. */
 #define SLAM_BA_LM_MAX_FREE 16
 #define SLAM_BA_LM_MAX_OBS (1 << 17)
 SLAM_API int slam_ba_optimize_workspace(int64_t K, int64_t L, int64_t O, uint64_t* bytes);
