@@ -532,7 +532,7 @@ __device__ __forceinline__ void bg_hpl(const ba_lin& q, double (&h)[6][3]) {
 // slice [begin, end) of pose k's observation list: Hpp (21), bp (6), y = sum Y_o bl (6), cost (1), stored as block `slot`
 // (what ba_obs_body + ba_pose_body do through the records)
 __device__ __forceinline__ void bg_pose(const bg_args& a, const double* __restrict__ X, const double* sT, int k, int begin, int end, int slot,
-                                        double (*sw)[34], double* out) {
+                                        const bool with_y, double (*sw)[34], double* out) {
     double acc[34];
 #pragma unroll
     for (int i = 0; i < 34; i++) acc[i] = 0.0;
@@ -551,9 +551,13 @@ __device__ __forceinline__ void bg_pose(const bg_args& a, const double* __restri
 #pragma unroll
         for (int u = 0; u < 4; u++) {
 #pragma unroll
-            for (int c = 0; c < 3; c++) { x[u][c] = X[(size_t)l[u] * 3 + c]; b[u][c] = a.bl[(size_t)l[u] * 3 + c]; }
+            for (int c = 0; c < 3; c++) x[u][c] = X[(size_t)l[u] * 3 + c];
+            if (with_y) {                       // (the launch's first pass runs beside the point phase: E and bl are not there yet)
 #pragma unroll
-            for (int c = 0; c < 9; c++) e[u][c] = a.E[(size_t)l[u] * 9 + c];
+                for (int c = 0; c < 3; c++) b[u][c] = a.bl[(size_t)l[u] * 3 + c];
+#pragma unroll
+                for (int c = 0; c < 9; c++) e[u][c] = a.E[(size_t)l[u] * 9 + c];
+            }
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -567,13 +571,15 @@ __device__ __forceinline__ void bg_pose(const bg_args& a, const double* __restri
                 for (int c = r; c < 6; c++) acc[t++] += q.w * (q.jp[0][r] * q.jp[0][c] + q.jp[1][r] * q.jp[1][c]);
 #pragma unroll
             for (int r = 0; r < 6; r++) acc[21 + r] += q.w * (q.jp[0][r] * q.e0 + q.jp[1][r] * q.e1);
-            double h[6][3];
-            bg_hpl(q, h);
+            if (with_y) {
+                double h[6][3];
+                bg_hpl(q, h);
 #pragma unroll
-            for (int r = 0; r < 6; r++) {
-                const double y0 = h[r][0] * e[u][0] + h[r][1] * e[u][3] + h[r][2] * e[u][6], y1 = h[r][0] * e[u][1] + h[r][1] * e[u][4] + h[r][2] * e[u][7],
-                             y2 = h[r][0] * e[u][2] + h[r][1] * e[u][5] + h[r][2] * e[u][8];
-                acc[27 + r] += y0 * b[u][0] + y1 * b[u][1] + y2 * b[u][2];
+                for (int r = 0; r < 6; r++) {
+                    const double y0 = h[r][0] * e[u][0] + h[r][1] * e[u][3] + h[r][2] * e[u][6], y1 = h[r][0] * e[u][1] + h[r][1] * e[u][4] + h[r][2] * e[u][7],
+                                 y2 = h[r][0] * e[u][2] + h[r][1] * e[u][5] + h[r][2] * e[u][8];
+                    acc[27 + r] += y0 * b[u][0] + y1 * b[u][1] + y2 * b[u][2];
+                }
             }
             acc[33] += q.rho;
         }
@@ -981,8 +987,10 @@ __global__ __launch_bounds__(BA_THREADS) void ba_lm_grid_kernel(const bg_args a)
             if (lane == 0) sw[wave][0] = hmax;
             __syncthreads();
             if (tid == 0) a.part[blk] = fmax(fmax(sw[0][0], sw[1][0]), fmax(sw[2][0], sw[3][0]));
+            __syncthreads();                                         // (sw is used again at once)
+        } else {
+            BG_SYNC_OR_QUIT();                                       // the first pass's pose tasks need nothing from the points
         }
-        BG_SYNC_OR_QUIT();
         // ---- per pose: Hpp, bp, y, cost; per pair of free poses: W.  A task (a pose's, or a pair's first pose's, observation
         //      list) is cut into nsub slices, one workgroup each; the consumers add the slices up in slice order.  The very
         //      first pass only measures the diagonal and the cost: it runs the pose tasks alone --------------------------------
@@ -999,7 +1007,7 @@ __global__ __launch_bounds__(BA_THREADS) void ba_lm_grid_kernel(const bg_args a)
                 }
                 const int p0 = s_ps_ptr[k1], p1 = s_ps_ptr[k1 + 1], len = (p1 - p0 + nsub - 1) / nsub;
                 const int begin = min(p1, p0 + sl * len), end = min(p1, begin + len);
-                if (task < K) bg_pose(a, X, sT, k1, begin, end, sl * K + k1, (double(*)[34])sw, out);
+                if (task < K) bg_pose(a, X, sT, k1, begin, end, sl * K + k1, lambda >= 0.0, (double(*)[34])sw, out);
                 else bg_pair(a, X, sT, k1, k2, begin, end, sl * npair + (task - K), sw, out);
                 __syncthreads();
             }

@@ -83,11 +83,12 @@ for b in range(nb):
 s2 = tr[0, 200:]
 s2 = (s2[s2 > 0] - t0) * 0.01
 print("workgroup 0 solve stamps (assembled, solved) per solve:", " ".join(f"{v:.2f}" for v in s2))
-# per accepted iteration after the first (rows 8..: points | camera blocks | solve | step), averaged
-if nb >= 12 and (nb - 8) % 4 == 0:
+# rows: 0-1 the observation table, 2 the first pass (points + pose tasks), then per trial points | camera blocks | solve |
+# step; averaged over the accepted trials after the first (rows 7..)
+if nb >= 11 and (nb - 7) % 4 == 0:
     names = ("points", "camera blocks", "solve", "step")
     work = np.zeros(4); bar = np.zeros(4); cnt = 0
-    for b0 in range(8, nb, 4):
+    for b0 in range(7, nb, 4):
         for x in range(4):
             b = b0 + x
             arrive, leave = us[:, 1 + 2 * b], us[:, 2 + 2 * b]
