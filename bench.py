@@ -28,7 +28,10 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
                   here) timed on the host cores over the same arrays (N = 1 only);
   pipelined     — with --pipelined: the same searches issued alternately on two contexts (N = 1 only; reported, not `value`);
   reproj        — the second hot path (residual/Jacobian build, 200 poses x 50k points dense)
-                  with its own HBM roofline (only at the default N=1 run).
+                  with its own HBM roofline (only at the default N=1 run);
+  next_rows     — the rows SURVEY.md 8f marks "next", as the calls a frame loop makes: one pose-only refinement (200 edges)
+                  and one window bundle adjustment at the reference's window, each beside the same loop in plain C on
+                  one host core and checked against it (N = 1 only; reported, not `value`; --no-next-rows skips it).
 """
 from __future__ import annotations
 
@@ -207,6 +210,76 @@ def reproj_bench(ctx, steps: int, warmup: int, cpu: bool = True) -> dict:
     return out
 
 
+def next_rows_leg(ctx, cpu: bool = True) -> dict:
+    """SURVEY.md 8f rows f3 / f4 beside one host core: the pose-only refinement of one frame (200 edges, the whole
+    `_correct_current_pose` schedule in one launch, frontend.py:298-393) and a window bundle adjustment at the reference's
+    window (7 keyframes, backend.py:11; five LM steps in one launch), each as the host-buffer call a frame loop would make,
+    with the plain-C statement of the same loop (oracle/pose_lm_oracle.c, oracle/ba_lm_oracle.c: test infrastructure, the
+    CPU baseline of these rows) timed on ONE core and compared with what the GPU returned.  Not part of `value`."""
+    sys.path.insert(0, os.path.join(ROOT, "slam-experiments_amd"))
+    from backend import Backend
+    from slamhip.ba import bundle_adjust_one_launch
+    from slamhip.pose_opt import se3_exp
+    from scipy.spatial.transform import Rotation
+
+    fx, fy, cx, cy = 458.654, 457.296, 367.215, 248.375
+    rng = np.random.default_rng(2026)
+    best = lambda f, n: min(_timed(f) for _ in range(n))
+    out = {}
+    # f3: one frame, 200 edges, every ninth a gross outlier, integer pixels as the reference's keypoints are
+    E = 200
+    X = np.c_[rng.uniform(-4, 4, (E, 2)), rng.uniform(6, 15, E)]
+    pix = np.c_[fx * X[:, 0] / X[:, 2] + cx, fy * X[:, 1] / X[:, 2] + cy] + rng.normal(0, 0.3, (E, 2))
+    pix[::9] += 70.0
+    pix = pix.astype(np.int32).astype(np.float64)
+    T0 = se3_exp([0.01, -0.01, 0.005, 0.05, -0.03, 0.04])
+    be = Backend()
+    call = lambda: be.optimize_pose(T0, X, pix, fx, fy, cx, cy, on_device=True)
+    r = call()
+    out["pose_lm"] = {"edges": E, "ms_per_call": best(call, 20) * 1e3, "accepted_steps": int(r.iterations), "inliers": int(r.n_inliers),
+                      "call": "Backend.optimize_pose (slam_pose_optimize_host_f64: one upload, one launch, one download)"}
+    if cpu:
+        from oracle import oracle
+        p12 = np.ascontiguousarray(T0[:3, :4].reshape(12))
+        ref = lambda: oracle.pose_lm_c(p12, X, pix, fx, fy, cx, cy)
+        Tc, inl_c, _, _ = ref()
+        out["pose_lm"]["cpu_baseline"] = {"ms_per_call": best(ref, 10) * 1e3, "cores": 1, "kind": "port", "sample": "the same frame, oracle/pose_lm_oracle.c"}
+        out["pose_lm"]["parity"] = bool(np.abs(r.pose[:3, :4] - np.asarray(Tc).reshape(-1)[:12].reshape(3, 4)).max() <= 1e-7 and np.array_equal(np.asarray(r.inliers, bool), np.asarray(inl_c, bool)))
+    # f4: the reference's window
+    K, L = 7, 1400
+    T = np.tile(np.eye(4), (K, 1, 1))
+    T[:, :3, :3] = Rotation.from_rotvec(rng.uniform(-0.15, 0.15, (K, 3))).as_matrix()
+    T[:, :3, 3] = rng.uniform(-0.5, 0.5, (K, 3))
+    P = np.c_[rng.uniform(-4, 4, (L, 2)), rng.uniform(6, 15, L)]
+    op = np.repeat(np.arange(K), L).astype(np.int32); ol = np.tile(np.arange(L), K).astype(np.int32)
+    keep = rng.uniform(size=K * L) < 0.6
+    op, ol = op[keep], ol[keep]
+    pc = np.einsum("oij,oj->oi", T[op, :3, :3], P[ol]) + T[op, :3, 3]
+    meas = np.c_[fx * pc[:, 0] / pc[:, 2] + cx, fy * pc[:, 1] / pc[:, 2] + cy] + rng.normal(0, 0.2, (len(op), 2))
+    Ts = np.stack([T[0], T[1]] + [se3_exp(rng.normal(0, 0.01, 6)) @ T[k] for k in range(2, K)])
+    Ps = P + rng.normal(0, 0.05, P.shape)
+    call = lambda: bundle_adjust_one_launch(Ts, Ps, op, ol, meas, (fx, fy, cx, cy), iterations=5, fixed_poses=(0, 1), ctx=ctx)
+    r = call()
+    out["window_ba"] = {"poses": K, "points": L, "observations": int(len(op)), "lm_steps": int(r.iterations), "ms_per_call": best(call, 20) * 1e3,
+                        "cost": [float(r.chi2_initial), float(r.chi2_final)],
+                        "call": "bundle_adjust_one_launch (slam_ba_optimize_host_f64: index tables, one upload, one launch, one download)"}
+    if cpu:
+        from oracle import oracle
+        p0 = np.ascontiguousarray(Ts[:, :3, :4]).reshape(K, 12)
+        ref = lambda: oracle.ba_lm_c(p0, Ps, op, ol, meas, fx, fy, cx, cy, 5, (0, 1), 0.0)
+        Tc, Xc, _, c1, acc, _ = ref()
+        out["window_ba"]["cpu_baseline"] = {"ms_per_call": best(ref, 5) * 1e3, "cores": 1, "kind": "port", "sample": "the same window, oracle/ba_lm_oracle.c"}
+        out["window_ba"]["parity"] = bool(acc == r.iterations and abs(c1 - r.chi2_final) <= 1e-9 * max(c1, 1.0) and np.abs(r.poses - Tc).max() <= 1e-8
+                                          and np.abs(r.points - Xc).max() <= 1e-7)
+    return out
+
+
+def _timed(f) -> float:
+    t0 = time.perf_counter()
+    f()
+    return time.perf_counter() - t0
+
+
 def pipelined_leg(query, train, steps: int) -> dict:
     """The same 64k x 64k searches issued alternately on two contexts of the one GPU (two streams, two merge states):
     the drain of one launch overlaps the start of the next.  Reported beside `value`, never as `value`: the contract's
@@ -311,6 +384,7 @@ def main() -> int:
                          "all-to-all (BASELINE configs[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reproj", action="store_true")
+    ap.add_argument("--no-next-rows", action="store_true", help="skip the pose-refinement / window-BA calls (SURVEY 8f rows f3, f4)")
     ap.add_argument("--pipelined", action="store_true",
                     help="also time the searches alternating between two contexts (extra object `pipelined`; off by default "
                          "so that a rocprofv3 summary of the default command only holds back-to-back launches)")
@@ -521,6 +595,11 @@ def main() -> int:
         out["pipelined"] = pipelined_leg(query, train, max(args.steps, 20))
     if rank == 0 and world == 1 and not args.no_reproj and not loop_closure:
         out["reproj"] = reproj_bench(ctx, max(3, min(args.steps, 20)), args.warmup, cpu=not args.no_cpu_baseline)
+    if rank == 0 and world == 1 and not args.no_next_rows and not loop_closure:
+        try:
+            out["next_rows"] = next_rows_leg(ctx, cpu=not args.no_cpu_baseline)
+        except Exception as exc:   # noqa: BLE001 - an extra leg must never cost the line
+            out["next_rows"] = {"error": f"{type(exc).__name__}: {exc}"}
     check_rc = 0
     if world > 1:
         check_rc = ctx.lib.slam_comm_destroy(ctx.handle) if collective == "rccl" else 0
