@@ -13,9 +13,9 @@ No CPU fallback: without the library or a gfx950 GPU the methods raise.
 """
 from __future__ import annotations
 
+import ast
 import importlib.util
 import os
-import re
 import sys
 from typing import Optional
 
@@ -29,19 +29,41 @@ from slamhip.device import Context, default_context
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-# What identifies the reference's backend.py (backend.py:10-12, :31): the Map container with its two tuning constants.
-_REFERENCE_MARKS = ("Map", "NUM_ACTIVE_KEYFRAMES", "MIN_DIST_THRESHOLD")
+# What identifies the reference's backend.py (backend.py:10-12): ``class Map`` whose body sets its two tuning constants.
+_REFERENCE_CONSTANTS = ("NUM_ACTIVE_KEYFRAMES", "MIN_DIST_THRESHOLD")
+
+
+def _assigned_names(body) -> set:
+    out = set()
+    for node in body:
+        targets = node.targets if isinstance(node, ast.Assign) else [node.target] if isinstance(node, ast.AnnAssign) else []
+        out.update(t.id for t in targets if isinstance(t, ast.Name))
+    return out
+
+
+def _reference_marks_missing(text: str):
+    """What a ``backend.py`` source lacks to be the reference's: a top-level ``class Map`` and the two constants, set
+    in the class body as the reference has them (``backend.py:10-12``) or at module level.  Parsed, never executed."""
+    try:
+        tree = ast.parse(text)
+    except SyntaxError as exc:
+        return [f"does not parse: {exc.msg}"]
+    classes = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "Map"]
+    if not classes:
+        return ["class Map"]
+    have = _assigned_names(tree.body) | _assigned_names(classes[-1].body)
+    return [c for c in _REFERENCE_CONSTANTS if c not in have]
 
 
 def _load_reference_backend():
     """Find the REFERENCE's ``backend.py`` on sys.path and load it; returns (module, report).
 
     An overlay install puts this directory ahead of the reference's on ``sys.path`` and both files are called
-    ``backend.py``.  A candidate is accepted only if its text defines the reference's ``Map`` class together with
-    ``NUM_ACTIVE_KEYFRAMES`` and ``MIN_DIST_THRESHOLD`` (``backend.py:10-12``) - checked on the source BEFORE anything
-    is executed, so an unrelated ``backend.py`` that happens to be on the path is neither imported nor mistaken for it.
-    The current working directory (the ``''`` entry) is considered only through that same test.  ``report`` lists what
-    was looked at, for the error message."""
+    ``backend.py``.  A candidate is accepted only if its source defines the reference's ``Map`` class with
+    ``NUM_ACTIVE_KEYFRAMES`` and ``MIN_DIST_THRESHOLD`` (class attributes, ``backend.py:10-12``) - checked on the
+    syntax tree BEFORE anything is executed, so an unrelated ``backend.py`` that happens to be on the path is neither
+    imported nor mistaken for it.  The current working directory (the ``''`` entry) is considered only through that
+    same test.  ``report`` lists what was looked at, for the error message."""
     seen, report = set(), []
     for entry in sys.path:
         base = os.path.abspath(entry or os.getcwd())
@@ -57,16 +79,17 @@ def _load_reference_backend():
         except OSError as exc:
             report.append(f"{cand}: unreadable ({exc})")
             continue
-        missing = [m for m in _REFERENCE_MARKS if not re.search(rf"^\s*(class\s+{m}\b|{m}\s*=)", text, re.M)]
+        missing = _reference_marks_missing(text)
         if missing:
             report.append(f"{cand}: not the reference's backend.py (no {', '.join(missing)})")
             continue
         spec = importlib.util.spec_from_file_location("_reference_backend", cand)
         mod = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(mod)
-        if all(hasattr(mod, m) for m in _REFERENCE_MARKS) and isinstance(mod.Map, type):
+        Map = getattr(mod, "Map", None)
+        if isinstance(Map, type) and all(hasattr(Map, c) or hasattr(mod, c) for c in _REFERENCE_CONSTANTS):
             return mod, report
-        report.append(f"{cand}: defines the names but not as a class and two constants")
+        report.append(f"{cand}: its source names Map and the two constants, but executing it did not define them")
     return None, report
 
 
@@ -118,7 +141,7 @@ class Backend:
         """Bundle adjustment over a window of keyframes and their landmarks (``optimizer.optimize(10)`` in
         spirit, ``frontend.py:362``; the reference's ``Backend`` has no body, ``backend.py:101-103``).
 
-        With ``on_device`` (default) a window of at most 16 moving poses and 20 000 observations (the reference keeps
+        With ``on_device`` (default) a window of at most 16 moving poses and 131 072 observations (the reference keeps
         7 keyframes, ``backend.py:11``) is optimised in ONE kernel launch (``slam_ba_optimize_f64``: the whole LM loop,
         dense solve included, on the device); larger windows run the linearisation, the elimination of the landmarks,
         the blocks of the reduced camera system and the back-substitution on the GPU (``slam_ba_reduce_f64`` /

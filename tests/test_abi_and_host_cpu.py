@@ -301,21 +301,32 @@ def test_map_discovery_skips_decoys_and_names_what_it_found(tmp_path):
     (decoy / "backend.py").write_text("raise SystemExit('the decoy was executed')\nclass Map: pass\n")
     half = tmp_path / "half"
     half.mkdir()
-    (half / "backend.py").write_text("NUM_ACTIVE_KEYFRAMES = 7\nclass Map:\n    pass\n")           # no MIN_DIST_THRESHOLD
-    standin = tmp_path / "ref"
+    (half / "backend.py").write_text("class Map:\n    NUM_ACTIVE_KEYFRAMES = 7\n")                # no MIN_DIST_THRESHOLD
+    nested = tmp_path / "nested"                                # the constants sit in some OTHER class: not the reference
+    nested.mkdir()
+    (nested / "backend.py").write_text("class Map:\n    pass\nclass Other:\n    NUM_ACTIVE_KEYFRAMES = 7\n    MIN_DIST_THRESHOLD = 0.2\n")
+    standin = tmp_path / "ref"                                  # the reference's layout: constants INSIDE class Map
     standin.mkdir()
-    (standin / "backend.py").write_text("NUM_ACTIVE_KEYFRAMES = 7\nMIN_DIST_THRESHOLD = 0.2\n\nclass Map:\n    marker = 'stand-in'\n")
+    (standin / "backend.py").write_text("class Map:\n    NUM_ACTIVE_KEYFRAMES = 7\n    MIN_DIST_THRESHOLD = 0.2\n    marker = 'stand-in'\n\n"
+                                        "class Backend:\n    def __init__(self):\n        pass\n")
+    legacy = tmp_path / "legacy"                                # constants at module level are accepted as well
+    legacy.mkdir()
+    (legacy / "backend.py").write_text("NUM_ACTIVE_KEYFRAMES = 7\nMIN_DIST_THRESHOLD: float = 0.2\n\nclass Map:\n    marker = 'legacy'\n")
     saved = list(sys.path)
     try:
         backend.__dict__.pop("Map", None)
-        sys.path[:0] = [str(decoy), str(half)]
+        sys.path[:0] = [str(decoy), str(half), str(nested)]
         with pytest.raises(ImportError) as err:
             backend.Map
         msg = str(err.value)
-        assert str(decoy) in msg and str(half) in msg and "MIN_DIST_THRESHOLD" in msg
+        assert str(decoy) in msg and str(half) in msg and str(nested) in msg and "MIN_DIST_THRESHOLD" in msg
         sys.path.append(str(standin))
         backend.__dict__.pop("Map", None)
-        assert backend.Map.marker == "stand-in"
+        assert backend.Map.marker == "stand-in" and backend.Map.NUM_ACTIVE_KEYFRAMES == 7
+        sys.path.remove(str(standin))
+        sys.path.append(str(legacy))
+        backend.__dict__.pop("Map", None)
+        assert backend.Map.marker == "legacy"
     finally:
         sys.path[:] = saved
         backend.__dict__.pop("Map", None)
