@@ -153,17 +153,23 @@ SLAM_API int slam_bf_knn2_u256_host(slam_ctx* ctx, const uint8_t* h_query, int64
  *                     queries, a multiple of 16 (shipped: 128, and the whole chunk for train sets below 16384 rows whose
  *                     chunks have at most 384 rows); -1 = none
  *   [7] chunk         rows per uniform chunk for train sets below 16384 rows, a multiple of 32 (shipped: one block per CU
- *                     up to 128 rows a chunk, about 8 sqrt(that) beyond, at most 512) */
-#define SLAM_BF_KNOBS 8
+ *                     up to 128 rows a chunk, about 8 sqrt(that) beyond, at most 512)
+ *   [8] queue         1 = a queue plan: as many worker blocks per query block as are resident at once, whose waves draw
+ *                     the chunks by ticket and keep their top-2 from chunk to chunk; -1 = one block per chunk (the plans
+ *                     above).  Shipped: a queue plan for train sets of at least 16384 rows when every query block gets at
+ *                     least two workers and they fill at least 80 % of the resident slots; then [7] forces the rows of a
+ *                     uniform chunk, [4] > 0 the shortest chunk at the end of the queue, [4] = -1 no shrinking chunks */
+#define SLAM_BF_KNOBS 9
 SLAM_API int slam_bf_set_tuning(slam_ctx* ctx, const int32_t* h_knobs, int count);
 /* The launch plan slam_bf_knn2_u256 would use for N x M on this context: h_plan int32 [10] =
  * {R, query blocks, uniform chunk rows, chunks, leader rows, leader chunks, shrinking tail chunks, CUs,
  *  feed (1 = train rows through SGPRs, 0 = through an LDS tile), unfiltered rows at a cold chunk start}. */
 SLAM_API int slam_bf_plan_info(slam_ctx* ctx, int64_t N, int64_t M, int32_t* h_plan);
 /* The same plan WITHOUT a device: a pure function of the CU count, the knobs (as slam_bf_set_tuning; NULL / 0 = shipped)
- * and the shape, so that the planner can be held to its invariants on a host without a GPU.  h_plan int32 [12] =
+ * and the shape, so that the planner can be held to its invariants on a host without a GPU.  h_plan int32 [14] =
  * slam_bf_plan_info's ten entries (h_plan[7] = num_cu) + {table-free: the kernel computes its chunk from the block index
- * and no boundary table is uploaded, bound-free: no block reads or writes a bound}.  The chunk boundary table (chunks + 1
+ * and no boundary table is uploaded, bound-free: no block reads or writes a bound, workers: worker blocks per query block
+ * of a queue plan (knob [8]; 0 = one block per chunk), resident: blocks per CU the planner counts on for that}.  The chunk boundary table (chunks + 1
  * ascending row indices from 0 to M) goes to h_tbl (up to tbl_cap entries; may be NULL) and its length to *tbl_len.
  * rows_on_host: the train rows lie in pinned host memory (frame-sized host calls).  qb_all: the query blocks of all the
  * searches that share the launch (slam_bf_knn2_batch_u256), 0 for a search that has the grid to itself. */
@@ -172,6 +178,10 @@ SLAM_API int slam_bf_plan_describe(int num_cu, const int32_t* h_knobs, int count
 /* Restore the matcher's per-context merge state to its idle values.  Every search leaves it clean by itself;
  * call this after a search failed part-way (the library does so on a failed launch).  Stream-ordered. */
 SLAM_API int slam_bf_reset_state(slam_ctx* ctx);
+/* Diagnostics: waits for the context's stream, then counts the 32-bit words of the merge state that are not at their idle
+ * value (*h_words; 0 after every completed search, whatever its plan).  A leftover would corrupt the next search silently,
+ * so the tests and tools/stress_state.py assert on this directly. */
+SLAM_API int slam_bf_state_dirty(slam_ctx* ctx, int64_t* h_words);
 
 /* Post-match selection on the device (feature_matchers.py:41-43 and the
  * OpenCV knn / ratio semantics).  Input: the [N,2] tables above.

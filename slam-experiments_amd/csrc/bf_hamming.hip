@@ -67,6 +67,8 @@ typedef uint32_t u32;
 #define SLAM_KEY_NONE 0xFFFFFFFFu
 #define SLAM_ACC_BIAS 0x80000000u
 #define SLAM_BOUND_IDLE 0x7F7F7F7Fu  // bound[] between launches (one byte pattern: restored by memset as well)
+#define SLAM_CURSOR_STRIDE 32       // u32 words between the cursors of two query waves (one 128-byte line each)
+#define SLAM_BF_RESIDENT 6          // blocks of bf_top2_kernel<1, true, true> a CU holds at once (106 SGPRs: 6 waves per SIMD); queue plans
 
 // D = popcount(x) + acc in ONE instruction.  Written as asm because hipcc
 // re-associates __builtin_popcount(x)+acc chains into bcnt(x,0)+v_add3 (20
@@ -211,16 +213,41 @@ __device__ __forceinline__ void insert_rows(const u32 (&acc)[U][R], u32 first_tr
 // 8192 x 65536 212 -> 222 us, 2000 x 2000 21 -> 33 us.)
 // gk[r] keeps the last bound seen (an upper bound of the final 2nd-best distance for good: bound[] only decreases
 // during a launch); the epilogue uses it to skip merges that cannot matter, without another round trip.
+#ifndef SLAM_EXP_SHARE
+#define SLAM_EXP_SHARE 2
+#endif
 template <int R>
 __device__ __forceinline__ void share_bound(u32* __restrict__ bound, int qbase, int N, const u32 (&b2)[R],
-                                            u32 (&init)[R], u32 (&gk)[R]) {
+                                            u32 (&init)[R], u32 (&gk)[R], u32 (&pend)[R]) {
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const int qi = qbase + r * 64;
         if (qi < N) {
-            const u32 g = __hip_atomic_load(&bound[qi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const u32 own = b2[r] >> SLAM_KEY_IDX_BITS;
+#if SLAM_EXP_SHARE == 0
+            u32 g;
+            if (own < gk[r] && own <= 256u) g = min(atomicMin(&bound[qi], own), own);   // what bound[] holds now
+            else g = __hip_atomic_load(&bound[qi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#elif SLAM_EXP_SHARE == 1
+            const u32 g = __hip_atomic_load(&bound[qi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (own < g) atomicMin(&bound[qi], own);
+#else
+            // The bound is READ with a relaxed agent-scope load.  A lane whose own 2nd-best beats it publishes it with an
+            // atomic minimum in the RETURNING form, whose value nobody waits for here: it is parked in pend[] and consumed
+            // at the lane's next exchange or in front of the arrival ticket (vector-memory operations return in issue
+            // order, so by then it has long arrived).  Returning on purpose: every write to bound[] is then known to have
+            // been performed at the memory side before the block's ticket is drawn, so none can land behind the last
+            // arriver's reset (a no-return atomic is only known to have been sent).
+            asm volatile("" ::"v"(pend[r]));
+            const u32 g = __hip_atomic_load(&bound[qi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#if SLAM_EXP_SHARE == 2
+            // Nothing is published while the lane has no 2nd neighbour yet (own = 511): a block that starts must still see
+            // "nobody has published" (SLAM_BOUND_IDLE) then.
+            if (own < g && own <= 256u) pend[r] = atomicMin(&bound[qi], own);
+#else
+            if (own < g) pend[r] = atomicMin(&bound[qi], own);
+#endif
+#endif
             gk[r] = g;
             init[r] = SLAM_ACC_BIAS - min(own, g + 1);
         }
@@ -228,12 +255,16 @@ __device__ __forceinline__ void share_bound(u32* __restrict__ bound, int qbase, 
 }
 
 // Per-query merge state shared by the blocks of one launch (device memory owned by the ctx).
-// Invariant between launches: best[] = ~0, bound[] = 0x7F7F7F7F, arrivals[] = 0; the last block
+// Invariant between launches: best[] = ~0, bound[] = 0x7F7F7F7F, arrivals[] = 0, cursor[] = 0; the last block
 // of every query block restores it after decoding, so no memset or merge kernel runs per call.
 struct bf_state {
     unsigned long long* best;   // [N]  (1st key << 32 | 2nd key), keys = dist << 23 | train row, ~0 = none
     u32* bound;                 // [N]  upper bound of the final 2nd-best distance (share_bound)
     u32* arrivals;              // [query blocks]  how many chunk blocks have merged their result
+    u32* cursor;                // [4 x query blocks] x SLAM_CURSOR_STRIDE  queue plans: the next chunk ticket of each query wave (0
+                                // between launches), every cursor on a 128-byte line of its own: returning atomics on one line
+                                // serialise at the memory side (with the 128 cursors of the 1/8 shard packed into four lines a
+                                // 256-row chunk cost 168 us where one block per chunk took 157: profiles/r04_ab_queue.log)
 };
 
 // grid.x = query blocks of 256*R rows, grid.y = train chunks: block (x, y) scans rows [tbl[y], tbl[y+1]).  Every block
@@ -245,23 +276,28 @@ struct bf_state {
 // with s_setprio (no change: as the oldest waves of their SIMDs they are served first anyway).
 // (bx, by) = the block's place in its search's grid of qblocks x S blocks: blockIdx of a single search, decoded from the
 // linear block index of a batch launch (bf_top2_batch_kernel).
-template <int R, bool SFEED>
+template <int R, bool SFEED, bool QUEUE>
 __device__ __forceinline__ void bf_top2_block(const uint4* __restrict__ q, int N, const uint4* __restrict__ t,
                                               const int* __restrict__ tbl, int lead, bf_state st, int train_base,
                                               int2* __restrict__ out_idx, int2* __restrict__ out_dist,
                                               uint4* __restrict__ keep, const int bx, const int by, const int S,
-                                              const int cold_arg, const int uni, const int M) {
+                                              const int cold_arg, const int uni_arg, const int M, const int nchunks) {
+    // QUEUE is a template parameter, not a run-time flag: with both forms in one kernel the one-block-per-chunk plans ran
+    // 1-2.5 % slower than without the queue code (30 SGPR spills instead of 3; profiles/r04_ab_queue.log).  A queue plan has
+    // a boundary table, exchanges bounds and has no leaders.
+    static_assert(!QUEUE || (SFEED && R == 1), "queue plans run the SGPR-fed scan at one query per lane");
+    const int uni = QUEUE ? 0 : uni_arg;
     __shared__ uint4 tile[2][SLAM_TILE_ROWS * 2 + 4];
     __shared__ u32 s_last;
     u32* __restrict__ bound = st.bound;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int qbase = bx * (256 * R) + wave * (64 * R) + lane;
-    const bool leader = by < lead;
+    const bool leader = !QUEUE && by < lead;
     // cold < 0 (make_plan): every chunk fits into its unfiltered start of -cold rows and the whole grid is resident at
     // once - no block could ever use a bound published by another, so none is read or written (one round trip less in
     // front of the scan).
-    const bool nobound = cold_arg < 0;
+    const bool nobound = !QUEUE && cold_arg < 0;
     const int cold = cold_arg < 0 ? -cold_arg : cold_arg;
 
     u32 qr[R][8];
@@ -279,9 +315,10 @@ __device__ __forceinline__ void bf_top2_block(const uint4* __restrict__ q, int N
         qr[r][0] = a.x; qr[r][1] = a.y; qr[r][2] = a.z; qr[r][3] = a.w;
         qr[r][4] = b.x; qr[r][5] = b.y; qr[r][6] = b.z; qr[r][7] = b.w;
     }
-    u32 b1[R], b2[R], init[R], gk[R];
+    u32 b1[R], b2[R], init[R], gk[R], pend[R];
 #pragma unroll
     for (int r = 0; r < R; r++) {
+        pend[r] = 0u;
         b1[r] = SLAM_KEY_NONE;
         b2[r] = SLAM_KEY_NONE;
         init[r] = SLAM_ACC_BIAS - (SLAM_KEY_NONE >> SLAM_KEY_IDX_BITS);  // "distance 511": everything enters
@@ -303,59 +340,134 @@ __device__ __forceinline__ void bf_top2_block(const uint4* __restrict__ q, int N
 
     // uni > 0: the plan is `uni` rows per chunk throughout (single-round launches: frame-sized searches and everything up
     // to a few thousand rows a side) - no boundary table to read, and none to upload in front of the launch
-    const int t0 = uni ? by * uni : tbl[by];
-    const int t1 = uni ? min(M, t0 + uni) : tbl[by + 1];
-
     if constexpr (SFEED) {
         // Train rows reach the lanes through SGPRs (SLAM_SCAN_GROUPS_ASM, bf_scan_sgpr.h): no LDS tile, no barrier, every
-        // wave scans the chunk on its own.  The bound is exchanged where the LDS form does it: at the start, after 16 /
-        // 32 / 64 / 128 rows (a block starts with no threshold of its own, so early on nearly every group takes the
-        // update path and what the sibling blocks have scanned meanwhile tightens it), then once per 256 rows.
+        // wave scans on its own.  The bound is exchanged where the LDS form does it: at the start, after 16 / 32 / 64 /
+        // 128 rows of a wave's FIRST chunk (it starts with no threshold of its own, so early on nearly every group takes
+        // the update path and what the sibling blocks have scanned meanwhile tightens it), then once per 256 rows.
         // The scalar loads run only four rows ahead, which covers an L2 hit but not a miss: each wave therefore TOUCHES
         // the 128-byte lines of the 256 rows after the stretch it is scanning with one vector load (lanes 0-15 of wave w:
         // lines 16 w .. 16 w + 15 of those 8 KiB) - what the LDS form's tile loads do as a side effect.  Measured
         // (profiles/r03_ab_sgpr_feed.log): 1000 x 3000 17.5 -> 13.9 us, 8192 x 8192 54.6 -> 48.9 us with the touch.
+        //
+        // QUEUE plans (nchunks > 0; round 4): grid.y is not the number of chunks but the number of WORKER blocks per query
+        // block - as many as are resident at once - and every wave draws its chunks itself: a ticket from the cursor of
+        // its query wave (one returning agent-scope atomic add, issued beside the bound exchange of the chunk, so it adds
+        // no round trip), chunk = tbl[ticket] .. tbl[ticket + 1], until the tickets run out.  A wave keeps its top-2 and
+        // its threshold from chunk to chunk: ONE start without a threshold, ONE merge and ONE arrival per worker instead
+        // of one per chunk, no dispatch of a new block between chunks, and the waves of a SIMD stay busy until the queue
+        // of their query wave is empty - the chunks shrink towards its end (make_plan_core), so they all run out of work
+        // within a few dozen rows of each other.  Nobody waits for anybody: the only exit condition is ticket >= nchunks,
+        // which every wave reaches because the cursor only grows.  Blocks that are dispatched after the queue has run
+        // dry (a device shared with another process) draw a ticket past the end, merge nothing and arrive.
         static_assert(!SFEED || R == 1, "the SGPR-fed scan holds one query per lane");
         const char* tbytes = (const char*)t;
-        auto touch = [&](int first) -> u32 {
-            const long long off = (long long)first * SLAM_DESC_BYTES + (wave * 16 + lane) * 128;
+        constexpr bool queue = QUEUE;
+        u32* const cursor = st.cursor + (size_t)(4 * bx + wave) * SLAM_CURSOR_STRIDE;
+        // One round trip per chunk: a queue worker draws its tickets ONE CHUNK AHEAD - the draw for the next chunk and the
+        // touch of this chunk's first lines are issued, then the bound exchange, whose wait covers both; what a wave holds
+        // back that way is one chunk from the shrinking end of the queue.  (Nothing but the one touch of the rows behind
+        // the current stretch may be in flight when a scan statement starts: with a second vector load outstanding the
+        // compiler puts an s_waitcnt vmcnt(0) in front of the statement, i.e. a memory round trip in front of every
+        // stretch - 152 -> 157 us on the 1/8 shard, profiles/r04_ab_queue.log.)
+        auto draw = [&]() -> u32 {
             u32 v = 0;
-            if (lane < 16 && off < (long long)t1 * SLAM_DESC_BYTES) v = *(const u32*)(tbytes + off);
+            if (lane == 0) v = __hip_atomic_fetch_add(cursor, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return v;
         };
-        u32 warm = touch(t0);
-        asm volatile("" ::"v"(warm));                  // the first stretch: wait for it, the scan starts right away
-        int row = t0;
-        bool is_cold = cold >= 16;
-        while (row < t1) {
-            if (!nobound) share_bound<R>(bound, qbase, N, b2, init, gk);
-            const int done = row - t0;
-            is_cold = is_cold && done == 0 && (nobound || nobody_published());
-            const int seg = is_cold ? cold : (done < 16 ? 16 : (done < SLAM_TILE_ROWS ? done : SLAM_TILE_ROWS));
-            const int end = min(row + seg, t1);
-            warm = (done == 0 || done >= SLAM_TILE_ROWS) ? touch(row + SLAM_TILE_ROWS) : 0u;
-            int ng = __builtin_amdgcn_readfirstlane((end - row) >> 4);
-            if (ng > 0) {
-                const uint4* tp = t + 2 * (size_t)row;
-                u32 idx = (u32)__builtin_amdgcn_readfirstlane(row);
-                row += ng << 4;
-                if (is_cold) {
-                    SLAM_SCAN_GROUPS_COLD_ASM(qr[0], tp, ng, idx, b1[0], b2[0]);
-                    tighten();
-                } else {
-                    SLAM_SCAN_GROUPS_ASM(qr[0], tp, ng, idx, b1[0], b2[0], init[0]);
+#ifndef SLAM_EXP_QLOOP
+#define SLAM_EXP_QLOOP 5
+#endif
+        int ci = by;
+        u32 ticket = 0;
+        if (queue) {
+            ticket = draw();
+#if SLAM_EXP_QLOOP == 3
+            ci = __builtin_amdgcn_readfirstlane(ticket);
+#endif
+        }
+        bool fresh = true;                              // the wave has no threshold of its own yet (its first chunk)
+        while (true) {
+#if SLAM_EXP_QLOOP == 3
+            if (queue && ci >= nchunks) break;
+            const int c0 = uni ? ci * uni : tbl[ci];
+            const int c1 = uni ? min(M, c0 + uni) : tbl[ci + 1];
+#else
+            int c0 = 0, c1 = 0;
+            if (!queue) { c0 = uni ? ci * uni : tbl[ci]; c1 = uni ? min(M, c0 + uni) : tbl[ci + 1]; }
+#endif
+            auto touch = [&](int first) -> u32 {
+                // block plans: the four waves of a block share a chunk, each touches a quarter of the lines; queue plans:
+                // every wave has a chunk of its own and touches all 64 lines
+                const long long off = (long long)first * SLAM_DESC_BYTES + (queue ? lane : wave * 16 + lane) * 128;
+                u32 v = 0;
+                if ((queue || lane < 16) && off < (long long)c1 * SLAM_DESC_BYTES) v = *(const u32*)(tbytes + off);
+                return v;
+            };
+#if SLAM_EXP_QLOOP == 3
+            u32 warm = touch(c0);
+            if (!nobound) share_bound<R>(bound, qbase, N, b2, init, gk, pend);
+            asm volatile("" ::"v"(warm));                  // the chunk's first lines are there
+#else
+            u32 warm = 0;
+            if (!queue) warm = touch(c0);
+            if (!nobound) share_bound<R>(bound, qbase, N, b2, init, gk, pend);
+            if (queue) {
+                ci = __builtin_amdgcn_readfirstlane(ticket);
+                if (ci >= nchunks) break;
+                c0 = tbl[ci];
+                c1 = tbl[ci + 1];
+#if SLAM_EXP_QLOOP == 4
+                warm = touch(c0);
+#else
+                if (fresh) warm = touch(c0);
+#endif
+            }
+            asm volatile("" ::"v"(warm));
+#endif
+            int row = c0;
+            bool is_cold = fresh && cold >= 16 && (nobound || nobody_published());
+            bool shared = true;                            // the exchange in front of the chunk's first stretch is done
+            while (row < c1) {
+                if (!shared && !nobound) share_bound<R>(bound, qbase, N, b2, init, gk, pend);
+                shared = false;
+                const int done = row - c0;
+                is_cold = is_cold && done == 0;
+                const int seg = is_cold ? cold
+                                        : (!fresh ? SLAM_TILE_ROWS : (done < 16 ? 16 : (done < SLAM_TILE_ROWS ? done : SLAM_TILE_ROWS)));
+                const int end = min(row + seg, c1);
+                warm = (done == 0 || done >= SLAM_TILE_ROWS) ? touch(row + SLAM_TILE_ROWS) : 0u;
+                int ng = __builtin_amdgcn_readfirstlane((end - row) >> 4);
+                if (ng > 0) {
+                    const uint4* tp = t + 2 * (size_t)row;
+                    u32 idx = (u32)__builtin_amdgcn_readfirstlane(row);
+                    row += ng << 4;
+                    if (is_cold) {
+                        SLAM_SCAN_GROUPS_COLD_ASM(qr[0], tp, ng, idx, b1[0], b2[0]);
+                        tighten();
+                    } else {
+                        SLAM_SCAN_GROUPS_ASM(qr[0], tp, ng, idx, b1[0], b2[0], init[0]);
+                    }
                 }
+                is_cold = false;
+                for (; row < end; row++) {                 // fewer than 16 rows left: only at the end of the train set
+                    const uint4 x0 = t[2 * (size_t)row], y0 = t[2 * (size_t)row + 1];
+                    u32 acc1[1][R];
+                    row_acc<R>(qr, x0, y0, init, acc1[0]);
+                    filter_update<R, 1>(acc1, (u32)row, b1, b2, init);
+                }
+                asm volatile("" ::"v"(warm));              // the touch has landed (this keeps its register until here)
             }
-            is_cold = false;
-            for (; row < end; row++) {                 // fewer than 16 rows left: only at the end of the train set
-                const uint4 x0 = t[2 * (size_t)row], y0 = t[2 * (size_t)row + 1];
-                u32 acc1[1][R];
-                row_acc<R>(qr, x0, y0, init, acc1[0]);
-                filter_update<R, 1>(acc1, (u32)row, b1, b2, init);
-            }
-            asm volatile("" ::"v"(warm));              // the touch has landed (this keeps its register until here)
+            if (!queue) break;
+            fresh = false;
+            ticket = draw();
+#if SLAM_EXP_QLOOP == 3
+            ci = __builtin_amdgcn_readfirstlane(ticket);
+#endif
         }
     } else {
+        const int t0 = uni ? by * uni : tbl[by];
+        const int t1 = uni ? min(M, t0 + uni) : tbl[by + 1];
         // prologue: first tile -> LDS buffer 0
     #pragma unroll
         for (int i = 0; i < 2; i++) {
@@ -376,7 +488,7 @@ __device__ __forceinline__ void bf_top2_block(const uint4* __restrict__ q, int N
                     nxt[i] = g < 2 * t1 ? t[(size_t)g] : make_uint4(0, 0, 0, 0);
                 }
             }
-            if (!nobound) share_bound<R>(bound, qbase, N, b2, init, gk);
+            if (!nobound) share_bound<R>(bound, qbase, N, b2, init, gk, pend);
             const int cnt = __builtin_amdgcn_readfirstlane(min(SLAM_TILE_ROWS, t1 - tb));
             const uint4* tp = tile[buf];
             // software pipeline: the next row is read from LDS while the current one is computed (the last
@@ -421,7 +533,7 @@ __device__ __forceinline__ void bf_top2_block(const uint4* __restrict__ q, int N
                     insert_rows<R, U>(acc, (u32)(tb + j), b1, b2);
                 }
                 tighten();
-                if (j < cnt && !nobound) share_bound<R>(bound, qbase, N, b2, init, gk);
+                if (j < cnt && !nobound) share_bound<R>(bound, qbase, N, b2, init, gk, pend);
                 while (seg_end <= j) seg_end *= 2;
             }
             while (true) {
@@ -432,7 +544,7 @@ __device__ __forceinline__ void bf_top2_block(const uint4* __restrict__ q, int N
                     filter_update<R, U>(acc, (u32)(tb + j), b1, b2, init);
                 }
                 if (lim >= cnt) break;
-                if (!nobound) share_bound<R>(bound, qbase, N, b2, init, gk);
+                if (!nobound) share_bound<R>(bound, qbase, N, b2, init, gk, pend);
                 seg_end *= 2;
             }
             for (; j < cnt; j++) {
@@ -473,7 +585,10 @@ __device__ __forceinline__ void bf_top2_block(const uint4* __restrict__ q, int N
                 // leaders leave the 2nd key of everything merged so far as the bound (an upper bound of the final one:
                 // the low half only ever holds keys other than the smallest)
                 const u32 k2 = min(atomicMin(half, push), push);
-                if ((k2 >> SLAM_KEY_IDX_BITS) < gk[r]) atomicMin(&st.bound[qi], k2 >> SLAM_KEY_IDX_BITS);
+                if ((k2 >> SLAM_KEY_IDX_BITS) < gk[r]) {           // returning form, like every write to bound[] (share_bound)
+                    const u32 ob = atomicMin(&st.bound[qi], k2 >> SLAM_KEY_IDX_BITS);
+                    asm volatile("" ::"v"(ob));
+                }
             } else if (push != SLAM_KEY_NONE) {
                 // returning form on purpose: "the value is back" means the minimum has been taken at the memory side, which is
                 // what the arrival ticket below relies on (a no-return atomic is only known to have been sent)
@@ -492,6 +607,8 @@ __device__ __forceinline__ void bf_top2_block(const uint4* __restrict__ q, int N
     // 2000 x 2000 10.7 -> 9.4 us, the 1/8 shard 159.9 -> 154.8 us without it (profiles/r03_ab_cold_start.log; the guide
     // lists "agent atomics both sides" among the valid forms).  Placement-independent: nothing relies on which XCD a block
     // runs on.
+#pragma unroll
+    for (int r = 0; r < R; r++) asm volatile("" ::"v"(pend[r]));   // the parked returns of share_bound
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
@@ -523,16 +640,29 @@ __device__ __forceinline__ void bf_top2_block(const uint4* __restrict__ q, int N
         }
     }
     if (tid == 0) __hip_atomic_store(&st.arrivals[bx], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (QUEUE && tid < 4)   // every worker of this query block has arrived, so nobody draws a ticket any more
+        __hip_atomic_store(&st.cursor[(size_t)(4 * bx + tid) * SLAM_CURSOR_STRIDE], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <int R, bool SFEED>
+template <int R, bool SFEED, bool QUEUE>
 __global__ __launch_bounds__(256) void bf_top2_kernel(const uint4* __restrict__ q, int N,
                                                       const uint4* __restrict__ t, const int* __restrict__ tbl,
                                                       int lead, bf_state st, int train_base,
                                                       int2* __restrict__ out_idx, int2* __restrict__ out_dist,
-                                                      uint4* __restrict__ keep, int cold, int uni, int M) {
-    bf_top2_block<R, SFEED>(q, N, t, tbl, lead, st, train_base, out_idx, out_dist, keep, (int)blockIdx.x, (int)blockIdx.y,
-                            (int)gridDim.y, cold, uni, M);
+                                                      uint4* __restrict__ keep, int cold, int uni, int M,
+                                                      int nchunks) {
+    // Queue plans rotate the query blocks from one row of workers to the next: worker y of query block x is block
+    // ((x - y) mod grid.x, y).  Blocks go to the XCDs round robin by their linear index, so without the rotation ALL workers
+    // of a query block sit on one XCD (grid.x is a multiple of 8 for the big grids) - and the XCDs do not run at the same
+    // pace: the queues of the query blocks of one XCD ran dry 5 % later than those of another (65536 x 65536: 1070 .. 1125 us
+    // by XCD, profiles/r04_block_timeline.log), and nobody can help a queue but its own workers.  Rotated, every queue is
+    // served from all XCDs and the faster ones simply draw more tickets.  The dispatch order, hence the age mix of a
+    // queue's workers (the VALU arbiter serves older waves first), stays what it was: row y of the grid is worker y of
+    // every query block.
+    int bx = (int)blockIdx.x;
+    if (QUEUE) bx = (bx + (int)blockIdx.y) % (int)gridDim.x;
+    bf_top2_block<R, SFEED, QUEUE>(q, N, t, tbl, lead, st, train_base, out_idx, out_dist, keep, bx, (int)blockIdx.y,
+                            (int)gridDim.y, cold, uni, M, nchunks);
 }
 
 // ---- several independent searches in ONE launch -------------------------------------------------------------------
@@ -559,11 +689,11 @@ __global__ __launch_bounds__(256) void bf_top2_batch_kernel(const bf_batch b) {
     const int local = id - p.first_block;           // x fastest, as in the single search: consecutive blocks = consecutive query blocks
     const int bx = local % p.qblocks, by = local / p.qblocks;
     if (p.sfeed)   // block-uniform: the search's train rows travel through SGPRs (short or long chunks in device memory)
-        bf_top2_block<1, true>(p.q, p.N, p.t, p.tbl, p.lead, p.st, p.train_base, p.out_idx, p.out_dist, p.keep, bx, by, p.S, p.cold,
-                               p.uni, p.M);
+        bf_top2_block<1, true, false>(p.q, p.N, p.t, p.tbl, p.lead, p.st, p.train_base, p.out_idx, p.out_dist, p.keep, bx, by, p.S, p.cold,
+                               p.uni, p.M, 0);
     else
-        bf_top2_block<1, false>(p.q, p.N, p.t, p.tbl, p.lead, p.st, p.train_base, p.out_idx, p.out_dist, p.keep, bx, by, p.S, p.cold,
-                                p.uni, p.M);
+        bf_top2_block<1, false, false>(p.q, p.N, p.t, p.tbl, p.lead, p.st, p.train_base, p.out_idx, p.out_dist, p.keep, bx, by, p.S, p.cold,
+                                p.uni, p.M, 0);
 }
 
 // merge G decoded tables by (dist, idx)
@@ -613,6 +743,8 @@ struct bf_plan {
     int sfeed;       // 1: train rows through SGPRs (bf_scan_sgpr.h), 0: through an LDS tile
     int cold;        // rows a chunk that starts without any bound folds in unfiltered (a multiple of 16; 0 = none)
     int uni;         // > 0: every chunk has this many rows (no leaders, no tail) and the kernel needs no boundary table
+    int workers;     // > 0: a QUEUE plan - grid.y = this many worker blocks per query block, whose waves draw the S chunks
+                     // of the table by ticket (bf_top2_block); 0: one block per chunk, grid.y = S
 };
 
 static int bf_check_knobs(const int* k) {
@@ -625,6 +757,8 @@ static int bf_check_knobs(const int* k) {
     SLAM_REQUIRE(!(k[5] == 1 && k[0] > 1), "the SGPR-fed scan holds one query per lane (R = 1)");
     SLAM_REQUIRE(k[6] >= -1 && k[6] <= (1 << 20) && (k[6] < 0 || k[6] % 16 == 0), "cold must be -1 or a multiple of 16 rows");
     SLAM_REQUIRE(k[7] >= 0 && k[7] <= (1 << 22) && k[7] % 32 == 0, "chunk must be a multiple of 32 rows");
+    SLAM_REQUIRE(k[8] >= -1 && k[8] <= 1, "queue must be 0 (heuristic), 1 (workers draw chunks by ticket) or -1 (one block per chunk)");
+    SLAM_REQUIRE(!(k[8] == 1 && (k[0] > 1 || k[5] == -1)), "a queue plan runs the SGPR-fed scan at one query per lane");
     return SLAM_OK;
 }
 
@@ -804,6 +938,43 @@ static bf_plan make_plan_core(int num_cu, const int* k, int64_t N, int64_t M, st
     p.uni = p.tail == 0 && p.lead == 0 ? p.chunk : 0;
     // one round and no chunk longer than the unfiltered start: the kernel exchanges no bounds at all (passed as -cold)
     if (qb_launch * (int64_t)p.S <= slots && p.chunk <= p.cold && p.lead == 0) p.cold = -p.cold;   // (S: the tail's extra chunks counted)
+    p.workers = 0;
+    // ---- queue plan (round 4): as many worker blocks per query block as are resident at once; their waves draw the chunks
+    // of the table by ticket and keep their top-2 from chunk to chunk (bf_top2_block).  What it removes is what made the
+    // 1/8 query shard of an 8-GPU run 27 % less efficient than the full grid: 137 starts without a
+    // threshold, merges and arrivals per query where 48 do, the gaps between a block's end and its successor's first row,
+    // and a drain of 40 us in which the last dispatch round thinned out (profiles/r03_block_timeline.log).
+    // The table: uniform chunks of c rows (256 for a shard, up to 1024 when a worker has thousands of rows to itself), and
+    // from the point where the rest would give every worker fewer than two of those, chunks of (rest / 2 workers) rows,
+    // never fewer than 32: the waves of a query run out of work within a few dozen rows of each other.
+    const int64_t resident = (int64_t)num_cu * SLAM_BF_RESIDENT;
+    const int64_t W = resident / p.qblocks > 1 ? resident / p.qblocks : 1;   // (forced on a grid of many dispatch rounds: one)
+    const bool can_queue = p.R == 1 && k[5] != -1 && !rows_on_host && qb_all <= p.qblocks && (M >= 16384 || k[8] == 1) && W >= 1;
+    const bool want_queue = k[8] == 1 || (k[8] == 0 && W >= 2 && W * p.qblocks * 10 >= resident * 8 && M >= 512 * W);
+    if (can_queue && want_queue) {
+        int64_t c = k[7] ? k[7] : 256;
+        const int64_t c_floor = (M / 3000 + 255) / 256 * 256;               // keeps the table within one ring slot
+        if (c < c_floor) c = c_floor;
+        const bool guided = k[4] >= 0;
+        const int64_t cmin = k[4] > 0 ? (k[4] + 15) / 16 * 16 : 64;
+        b.clear();
+        b.push_back(0);
+        int shrinking = 0;
+        for (int64_t at = 0; at < M;) {
+            int64_t len = c;
+            if (guided) {
+                const int64_t g = (M - at) / (2 * W) / 16 * 16;
+                if (g < len) { len = g < cmin ? cmin : g; shrinking++; }
+            }
+            at = at + len < M ? at + len : M;
+            b.push_back((int)at);
+        }
+        p.chunk = (int)c;
+        p.S = (int)b.size() - 1;
+        p.lead = 0; p.lead_rows = 0; p.tail = shrinking; p.uni = 0; p.sfeed = 1;
+        p.cold = k[6] < 0 ? 0 : (k[6] ? k[6] : SLAM_COLD_ROWS);
+        p.workers = (int)(W < p.S ? W : p.S);
+    }
     return p;
 }
 
@@ -814,8 +985,9 @@ static bf_plan make_plan(slam_ctx* ctx, int64_t N, int64_t M, std::vector<int>* 
 }
 
 // The launch plan for N x M on a device with `num_cu` CUs under `count` knobs (as slam_bf_set_tuning; NULL / 0 = shipped),
-// WITHOUT a device: h_plan int32 [12] = slam_bf_plan_info's ten entries (h_plan[7] = num_cu) + {table-free (1 = the kernel
-// computes its chunk from the block index), bound-free (1 = no block reads or writes a bound)}; the chunk boundary table
+// WITHOUT a device: h_plan int32 [14] = slam_bf_plan_info's ten entries (h_plan[7] = num_cu) + {table-free (1 = the kernel
+// computes its chunk from the block index), bound-free (1 = no block reads or writes a bound), worker blocks per query
+// block of a queue plan (0 = one block per chunk), resident blocks per CU the planner counts on}; the chunk boundary table
 // goes to h_tbl (up to tbl_cap entries; may be NULL) and its length to *tbl_len.  rows_on_host: the train rows lie in
 // pinned host memory (frame-sized host calls).  qb_all: query blocks of all searches sharing the launch (0 = alone).
 extern "C" int slam_bf_plan_describe(int num_cu, const int32_t* h_knobs, int count, int64_t N, int64_t M, int64_t qb_all,
@@ -832,6 +1004,7 @@ extern "C" int slam_bf_plan_describe(int num_cu, const int32_t* h_knobs, int cou
     h_plan[0] = p.R; h_plan[1] = p.qblocks; h_plan[2] = p.chunk; h_plan[3] = p.S;
     h_plan[4] = p.lead_rows; h_plan[5] = p.lead; h_plan[6] = p.tail; h_plan[7] = num_cu;
     h_plan[8] = p.sfeed; h_plan[9] = p.cold < 0 ? -p.cold : p.cold; h_plan[10] = p.uni ? 1 : 0; h_plan[11] = p.cold < 0 ? 1 : 0;
+    h_plan[12] = p.workers; h_plan[13] = SLAM_BF_RESIDENT;
     *tbl_len = (int64_t)tbl.size();
     for (int64_t i = 0; i < (int64_t)tbl.size() && i < tbl_cap; i++) h_tbl[i] = tbl[(size_t)i];
     return SLAM_OK;
@@ -851,12 +1024,17 @@ extern "C" int slam_bf_plan_info(slam_ctx* ctx, int64_t N, int64_t M, int32_t* h
 // merge state for up to N queries, kept clean between launches (see bf_state), followed by the chunk boundary table
 #define SLAM_BF_TBL_MAX 65536   // entries; grid.y <= 65535
 // (SLAM_BF_TBL_RING slots of SLAM_BF_TBL_SLOT entries + one slot of SLAM_BF_TBL_MAX: internal.h)
+static size_t bf_state_bytes(size_t rows) {      // best u64 [rows] + bound u32 [rows] + arrivals u32 [blocks] + padded cursors + alignment slack
+    const size_t blocks = (rows + 255) / 256;   // query blocks at R = 1, the finest split
+    return rows * 12 + blocks * 4 + blocks * 16 * SLAM_CURSOR_STRIDE + 128;
+}
+
 static int bf_state_fill(slam_ctx* ctx) {
     char* p = (char*)ctx->bf_state_mem;
-    const size_t rows = (size_t)ctx->bf_state_rows, blocks = (rows + 255) / 256;
+    const size_t rows = (size_t)ctx->bf_state_rows;
     SLAM_HIP(hipMemsetAsync(p, 0xFF, rows * 8, ctx->stream));
     SLAM_HIP(hipMemsetAsync(p + rows * 8, 0x7F, rows * 4, ctx->stream));
-    SLAM_HIP(hipMemsetAsync(p + rows * 12, 0, blocks * 4, ctx->stream));
+    SLAM_HIP(hipMemsetAsync(p + rows * 12, 0, bf_state_bytes(rows) - rows * 12, ctx->stream));   // arrivals, then the cursors
     return SLAM_OK;
 }
 
@@ -868,9 +1046,7 @@ static int bf_state_get(slam_ctx* ctx, int64_t N, bf_state* out) {
         ctx->bf_state_mem = nullptr;
         ctx->bf_state_rows = 0;
         const int64_t rows = N + (N >> 2) + 1024;                 // headroom: slightly larger calls do not realloc
-        const size_t blocks = (size_t)(rows + 255) / 256;         // query blocks at R = 1, the finest split
-        const size_t bytes = (size_t)rows * 12 + blocks * 4;
-        SLAM_HIP(hipMalloc(&ctx->bf_state_mem, bytes));
+        SLAM_HIP(hipMalloc(&ctx->bf_state_mem, bf_state_bytes((size_t)rows)));
         ctx->bf_state_rows = rows;
         if (int rc = bf_state_fill(ctx)) return rc;
     }
@@ -879,6 +1055,7 @@ static int bf_state_get(slam_ctx* ctx, int64_t N, bf_state* out) {
     out->best = (unsigned long long*)p;
     out->bound = (u32*)(p + rows * 8);
     out->arrivals = (u32*)(p + rows * 12);
+    out->cursor = (u32*)(((uintptr_t)(out->arrivals + (rows + 255) / 256) + 127) & ~(uintptr_t)127);
     return SLAM_OK;
 }
 
@@ -967,6 +1144,32 @@ extern "C" int slam_bf_reset_state(slam_ctx* ctx) {
     return bf_state_fill(ctx);
 }
 
+// How many 32-bit words of the merge state are NOT at their idle value (best = ~0, bound = 0x7F7F7F7F, arrivals = 0,
+// cursor = 0) once everything queued on the context has finished: 0 after any completed search.  For tests and soak tools:
+// a key, bound, ticket or cursor that survived a search would corrupt the next one silently.
+extern "C" int slam_bf_state_dirty(slam_ctx* ctx, int64_t* h_words) {
+    SLAM_REQUIRE(ctx && h_words, "slam_bf_state_dirty: null argument");
+    SLAM_HIP(hipSetDevice(ctx->device));
+    SLAM_HIP(hipStreamSynchronize(ctx->stream));
+    std::vector<u32> host;
+    size_t rows;
+    {
+        std::lock_guard<std::mutex> g(ctx->mu);
+        rows = (size_t)ctx->bf_state_rows;
+        *h_words = 0;
+        if (!ctx->bf_state_mem) return SLAM_OK;
+        host.resize(bf_state_bytes(rows) / 4);
+        SLAM_HIP(hipMemcpy(host.data(), ctx->bf_state_mem, host.size() * sizeof(u32), hipMemcpyDeviceToHost));
+    }
+    int64_t bad = 0;
+    for (size_t i = 0; i < host.size(); i++) {
+        const u32 idle = i < rows * 2 ? 0xFFFFFFFFu : (i < rows * 3 ? SLAM_BOUND_IDLE : 0u);
+        bad += host[i] != idle;
+    }
+    *h_words = bad;
+    return SLAM_OK;
+}
+
 // one pass over at most 2^23 train rows
 static int bf_pass(slam_ctx* ctx, const void* d_query, int64_t N, const void* d_train, int64_t M,
                    int64_t train_base, int32_t* d_idx, int32_t* d_dist, void* d_keep) {
@@ -977,7 +1180,17 @@ static int bf_pass(slam_ctx* ctx, const void* d_query, int64_t N, const void* d_
     const int* d_tbl = nullptr;
     if (!p.uni)
         if (int rc = bf_table_get(ctx, tbl, &d_tbl)) return rc;
-    const dim3 grid(p.qblocks, p.S), block(256);
+    int workers = p.workers;
+    if (workers) {
+        // the plan counts on SLAM_BF_RESIDENT blocks per CU; a build or device that holds fewer gets fewer workers (the
+        // table is the same: the waves simply draw more tickets each), never a second dispatch round of idle workers
+        int occ = 0;
+        SLAM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, bf_top2_kernel<1, true, true>, 256, 0));
+        const int64_t fit = (int64_t)ctx->num_cu * occ / p.qblocks;
+        if (fit >= 1 && fit < workers) workers = (int)fit;
+    }
+    const dim3 grid(p.qblocks, workers ? workers : p.S), block(256);
+    const int nchunks = workers ? p.S : 0;
     const uint4* q = (const uint4*)d_query;
     const uint4* t = (const uint4*)d_train;
     int2* oi = (int2*)d_idx;
@@ -985,15 +1198,16 @@ static int bf_pass(slam_ctx* ctx, const void* d_query, int64_t N, const void* d_
     const int tb = (int)train_base;
     SLAM_HIP(hipGetLastError());
     if (int rc = slam_prof_begin(ctx)) return rc;
-#define SLAM_BF_LAUNCH(R_, F_) \
-    bf_top2_kernel<R_, F_><<<grid, block, 0, ctx->stream>>>(q, (int)N, t, d_tbl, p.lead, st, tb, oi, od, (uint4*)d_keep, p.cold, p.uni, (int)M)
+#define SLAM_BF_LAUNCH(R_, F_, Q_) \
+    bf_top2_kernel<R_, F_, Q_><<<grid, block, 0, ctx->stream>>>(q, (int)N, t, d_tbl, p.lead, st, tb, oi, od, (uint4*)d_keep, p.cold, p.uni, (int)M, nchunks)
     switch (p.R) {
-        case 8: SLAM_BF_LAUNCH(8, false); break;
-        case 4: SLAM_BF_LAUNCH(4, false); break;
-        case 2: SLAM_BF_LAUNCH(2, false); break;
+        case 8: SLAM_BF_LAUNCH(8, false, false); break;
+        case 4: SLAM_BF_LAUNCH(4, false, false); break;
+        case 2: SLAM_BF_LAUNCH(2, false, false); break;
         default:
-            if (p.sfeed) SLAM_BF_LAUNCH(1, true);
-            else SLAM_BF_LAUNCH(1, false);
+            if (workers) SLAM_BF_LAUNCH(1, true, true);
+            else if (p.sfeed) SLAM_BF_LAUNCH(1, true, false);
+            else SLAM_BF_LAUNCH(1, false, false);
             break;
     }
 #undef SLAM_BF_LAUNCH
@@ -1095,7 +1309,7 @@ int slam_bf_knn2_batch_keep(slam_ctx* ctx, int64_t B, const slam_bf_search* h_se
         d.q = (const uint4*)h.d_query; d.t = (const uint4*)h.d_train;
         d.out_idx = (int2*)h.d_idx; d.out_dist = (int2*)h.d_dist;
         d.keep = h_keep ? (uint4*)h_keep[i] : nullptr;
-        d.st.best = st.best + row0; d.st.bound = st.bound + row0; d.st.arrivals = st.arrivals + row0 / 256;
+        d.st.best = st.best + row0; d.st.bound = st.bound + row0; d.st.arrivals = st.arrivals + row0 / 256; d.st.cursor = st.cursor + row0 / 64 * SLAM_CURSOR_STRIDE;
         d.N = (int)h.N; d.lead = p.lead; d.S = p.S; d.qblocks = p.qblocks; d.train_base = (int)h.train_base;
         d.first_block = blocks; d.cold = p.cold; d.uni = p.uni; d.M = (int)h.M; d.sfeed = p.sfeed;
         tbl_at.push_back(tables.size());

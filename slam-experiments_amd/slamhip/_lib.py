@@ -56,6 +56,7 @@ SIGNATURES = {
     "slam_bf_plan_describe": (c_int, [c_int, POINTER(c_int32), c_int, c_int64, c_int64, c_int64, c_int, POINTER(c_int32),
                                       POINTER(c_int32), c_int64, POINTER(c_int64)]),
     "slam_bf_reset_state": (c_int, [c_void_p]),
+    "slam_bf_state_dirty": (c_int, [c_void_p, POINTER(c_int64)]),
     "slam_bf_match_filter": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_double, c_void_p,
                                      POINTER(c_int64), POINTER(c_int32)]),
     "slam_bf_cross_check": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,

@@ -79,10 +79,17 @@ class Context:
         return self.malloc(host.nbytes).upload(host)
 
     def set_tuning(self, R: int = 0, blocks_per_cu: int = 0, lead_rows: int = 0, lead_chunk: int = 0,
-                   tail: int = 0, feed: int = 0, cold: int = 0, chunk: int = 0) -> None:
+                   tail: int = 0, feed: int = 0, cold: int = 0, chunk: int = 0, queue: int = 0) -> None:
         """Experiment knobs of the top-2 search on this context (``slam_bf_set_tuning``); no arguments = shipped plan."""
-        knobs = (ctypes.c_int32 * 8)(R, blocks_per_cu, lead_rows, lead_chunk, tail, feed, cold, chunk)
-        check(self.lib.slam_bf_set_tuning(self.handle, knobs, 8))
+        knobs = (ctypes.c_int32 * 9)(R, blocks_per_cu, lead_rows, lead_chunk, tail, feed, cold, chunk, queue)
+        check(self.lib.slam_bf_set_tuning(self.handle, knobs, 9))
+
+    def state_dirty(self) -> int:
+        """Words of the search's merge state that are not idle once the stream has drained (``slam_bf_state_dirty``):
+        0 after every completed search."""
+        n = ctypes.c_int64(-1)
+        check(self.lib.slam_bf_state_dirty(self.handle, ctypes.byref(n)))
+        return n.value
 
     def plan_info(self, n: int, m: int) -> dict:
         """The launch plan the top-2 search would use for n x m (``slam_bf_plan_info``)."""
@@ -124,7 +131,7 @@ def default_context() -> Context:
         return _default_ctx
 
 
-PLAN_KNOBS = ("R", "blocks_per_cu", "lead_rows", "lead_chunk", "tail", "feed", "cold", "chunk")
+PLAN_KNOBS = ("R", "blocks_per_cu", "lead_rows", "lead_chunk", "tail", "feed", "cold", "chunk", "queue")
 
 
 def plan_describe(n: int, m: int, num_cu: int = 256, qb_all: int = 0, rows_on_host: bool = False, **knobs):
@@ -135,11 +142,11 @@ def plan_describe(n: int, m: int, num_cu: int = 256, qb_all: int = 0, rows_on_ho
         raise TypeError(f"unknown knobs {sorted(unknown)}")
     lib = _lib.load()
     k = (ctypes.c_int32 * len(PLAN_KNOBS))(*(int(knobs.get(name, 0)) for name in PLAN_KNOBS))
-    plan = (ctypes.c_int32 * 12)()
+    plan = (ctypes.c_int32 * 14)()
     cap = 1 << 16
     tbl = (ctypes.c_int32 * cap)()
     length = ctypes.c_int64(0)
     check(lib.slam_bf_plan_describe(num_cu, k, len(PLAN_KNOBS), n, m, qb_all, int(rows_on_host), plan, tbl, cap, ctypes.byref(length)))
     names = ("R", "qblocks", "chunk", "chunks", "lead_rows", "lead_chunks", "tail_chunks", "cus", "sgpr_feed", "cold_rows",
-             "table_free", "bound_free")
+             "table_free", "bound_free", "workers", "resident")
     return dict(zip(names, plan)), list(tbl[:min(length.value, cap)])

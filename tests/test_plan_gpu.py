@@ -42,6 +42,16 @@ def test_every_plan_shape_is_bit_identical(gpu_ctx, n, m):
                                            cold=cold)
                             idx, dist = _search(ctx, dq, n, dt, m, tab)
                             assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist), (R, lead_rows, lead_chunk, bpc, tail, feed, cold)
+        assert ctx.state_dirty() == 0
+        # queue plans (round 4): resident workers whose waves draw the chunks by ticket - any uniform chunk, shortest chunk
+        # and unfiltered start; with and without the shrinking end of the queue
+        for chunk in (0, 32, 64, 512):
+            for tail in (0, -1, 16, 48):
+                for cold in (0, -1, 16, 1024):
+                    ctx.set_tuning(queue=1, chunk=chunk, tail=tail, cold=cold)
+                    idx, dist = _search(ctx, dq, n, dt, m, tab)
+                    assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist), ("queue", chunk, tail, cold)
+                    assert ctx.state_dirty() == 0, ("queue", chunk, tail, cold)
     finally:
         ctx.set_tuning()
         for o in (tab, dq, dt):
@@ -88,11 +98,12 @@ def test_plan_tables_and_degenerate_inputs(gpu_ctx):
     from oracle import oracle
 
     ctx = gpu_ctx
-    for m, lead in ((200, 0), (16383, 0), (16384, 2048), (65536, 8192), (1 << 20, 8192)):
-        p = ctx.plan_info(8192, m)
-        assert p["lead_rows"] == lead and (p["lead_chunks"] > 0) == (lead > 0), (m, p)
     try:
-        ctx.set_tuning(lead_rows=1000, lead_chunk=96, tail=9, blocks_per_cu=16)
+        ctx.set_tuning(queue=-1)
+        for m, lead in ((200, 0), (16383, 0), (16384, 2048), (65536, 8192), (1 << 20, 8192)):
+            p = ctx.plan_info(8192, m)
+            assert p["lead_rows"] == lead and (p["lead_chunks"] > 0) == (lead > 0), (m, p)
+        ctx.set_tuning(lead_rows=1000, lead_chunk=96, tail=9, blocks_per_cu=16, queue=-1)
         p = ctx.plan_info(5000, 30000)
         assert p["lead_rows"] == 992 and p["lead_chunks"] == 11 and p["tail_chunks"] == 9 and p["chunks"] > 20
     finally:
@@ -123,13 +134,14 @@ def test_plan_tables_and_degenerate_inputs(gpu_ctx):
             t[rows] = q                                         # every query has an exact copy in / behind the leader rows
         ridx, rdist = oracle.bf_knn_c(q, t, 2, threads=8)
         for wait in (0, 1):
-            for feed in (-1, 1):
+            for feed, queue in ((-1, 0), (1, -1), (1, 1)):
                 try:
-                    ctx.set_tuning(lead_rows=-wait, tail=7 * wait, feed=feed)
+                    ctx.set_tuning(lead_rows=-wait, tail=7 * wait, feed=feed, queue=queue)
                     idx, dist = slamhip.knn_match_arrays(q, t, 2, ctx=ctx)
                 finally:
                     ctx.set_tuning()
-                assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist), (case, wait, feed)
+                assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist), (case, wait, feed, queue)
+                assert ctx.state_dirty() == 0
 
 
 def test_reset_state_between_searches(gpu_ctx):
@@ -144,4 +156,45 @@ def test_reset_state_between_searches(gpu_ctx):
     for _ in range(2):
         idx, dist = slamhip.knn_match_arrays(q, t, 2, ctx=ctx)
         assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist)
+        assert ctx.state_dirty() == 0                     # every search leaves best / bound / arrivals / cursors idle by itself
         assert lib.slam_bf_reset_state(ctx.handle) == 0
+        assert ctx.state_dirty() == 0
+
+
+def test_queue_plan_is_what_large_searches_run_and_it_leaves_the_state_idle(gpu_ctx):
+    """The shipped plan of a query shard (8192 x 65536: the per-rank problem of an 8-GPU run) is a queue of resident workers;
+    it is bit-identical to the one-block-per-chunk plan and to the oracle on sampled rows, planted ties across chunk
+    boundaries included, and no key, bound, ticket or cursor survives the launch (asserted on the state itself,
+    not inferred from later results)."""
+    import slamhip
+    from oracle import oracle
+
+    ctx = gpu_ctx
+    n, m = 8192, 65536
+    p, tbl = slamhip.plan_describe(n, m, num_cu=ctx.plan_info(n, m)["cus"])
+    assert p["workers"] >= 2 and p["workers"] * p["qblocks"] <= p["cus"] * p["resident"]
+    rng = np.random.default_rng(2026)
+    q = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    t = rng.integers(0, 256, (m, 32), dtype=np.uint8)
+    for i, b in enumerate(tbl[1:40]):                      # copies of query i on both sides of chunk boundaries: (0, b - 1) and (0, b)
+        t[b - 1] = q[2 * i]
+        t[b] = q[2 * i + 1]
+        t[m - 1 - i] = q[2 * i]                            # and once more in the short chunks at the end of the queue
+    dq, dt = slamhip.DeviceDescriptors(ctx, q), slamhip.DeviceDescriptors(ctx, t)
+    tab = slamhip.Top2Table(ctx, n)
+    try:
+        got = {}
+        for queue in (0, -1, 1):
+            ctx.set_tuning(queue=queue)
+            got[queue] = _search(ctx, dq, n, dt, m, tab)
+            assert ctx.state_dirty() == 0, queue
+        for queue in (-1, 1):
+            assert np.array_equal(got[0][0], got[queue][0]) and np.array_equal(got[0][1], got[queue][1]), queue
+        rows = np.r_[np.arange(80), rng.choice(n, 300, replace=False)]
+        ridx, rdist = oracle.bf_knn_c(q[rows], t, 2, threads=8)
+        assert np.array_equal(got[0][0][rows], ridx) and np.array_equal(got[0][1][rows], rdist)
+        assert got[0][0][0].tolist() == [tbl[1] - 1, m - 1] and got[0][1][0].tolist() == [0, 0]
+    finally:
+        ctx.set_tuning()
+        for o in (tab, dq, dt):
+            o.free()

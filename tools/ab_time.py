@@ -3,7 +3,7 @@
 
     python tools/ab_time.py LIB[:k=v...][,LIB...] [NxM ...] [--rounds R] [--reps K] [--check]
 
-A library may carry tuning knobs of slam_bf_set_tuning, e.g. path/libslamhip.so:R=2:bpc=16 (R, bpc, lead, leadchunk, tail, feed, cold, chunk).
+A library may carry tuning knobs of slam_bf_set_tuning, e.g. path/libslamhip.so:R=2:bpc=16 (R, bpc, lead, leadchunk, tail, feed, cold, chunk, queue).
 
 Each library is dlopen'ed privately (RTLD_LOCAL; the builds export the same symbols), gets its own context and its
 own copy of the inputs.  Per round and library: K back-to-back searches between two HIP events.  --check compares
@@ -50,8 +50,8 @@ class Lib:
         self.ctx = ctypes.c_void_p()
         assert self.lib.slam_ctx_create(0, ctypes.byref(self.ctx)) == 0, self.lib.slam_last_error()
         if knobs:
-            names = ("R", "bpc", "lead", "leadchunk", "tail", "feed", "cold", "chunk")
-            nk = 8 if ("cold" in knobs or "chunk" in knobs) else 6      # older builds know six knobs
+            names = ("R", "bpc", "lead", "leadchunk", "tail", "feed", "cold", "chunk", "queue")
+            nk = 9 if "queue" in knobs else (8 if ("cold" in knobs or "chunk" in knobs) else 6)      # older builds know six / eight knobs
             k = (ctypes.c_int32 * nk)(*(knobs.get(n, 0) for n in names[:nk]))
             assert self.lib.slam_bf_set_tuning(self.ctx, k, nk) == 0, self.lib.slam_last_error()
 

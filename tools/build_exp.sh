@@ -23,7 +23,7 @@ src = open(sys.argv[1]).read()
 T = '    if (tid == 0 && g_trace) { g_trace[4*(by*(int)gridDim.x+bx)+%d] = wall_clock64(); }\n'
 s = src.replace('    const bool leader = by < lead;\n', T % 0 + '    const bool leader = by < lead;\n', 1)
 s = s.replace('        int buf = 0;\n', '    ' + T % 1 + '        int buf = 0;\n', 1)
-s = s.replace('        int row = t0;\n', '    ' + T % 1 + '        int row = t0;\n', 1)
+s = s.replace('        bool fresh = true;', T % 1 + '        bool fresh = true;', 1)
 s = s.replace('    // ---- epilogue: merge,', T % 2 + '    // ---- epilogue: merge,', 1)
 s = s.replace('    if (!s_last) return;\n', T % 3 + '    if (!s_last) return;\n', 1)
 s = s.replace('typedef uint32_t u32;', 'typedef uint32_t u32;\n__device__ unsigned long long* g_trace = nullptr;\n'
@@ -49,7 +49,7 @@ C = ('    if (g_cyc) { unsigned long long c_, r_; asm volatile("s_memtime %%0\\n
      '        if (tid == 0) { g_cyc[8*(by*(int)gridDim.x+bx)+%d] = c_; g_cyc[8*(by*(int)gridDim.x+bx)+%d] = r_; } }\n')
 y = src.replace('    const bool leader = by < lead;\n', C % (0, 1) + '    const bool leader = by < lead;\n', 1)
 y = y.replace('        int buf = 0;\n', C % (2, 3) + '        int buf = 0;\n', 1)
-y = y.replace('        int row = t0;\n', C % (2, 3) + '        int row = t0;\n', 1)
+y = y.replace('        bool fresh = true;', C % (2, 3) + '        bool fresh = true;', 1)
 y = y.replace('    // ---- epilogue: merge,', C % (4, 5) + '    // ---- epilogue: merge,', 1)
 y = y.replace('    if (!s_last) return;\n', C % (6, 7) + '    if (!s_last) return;\n', 1)
 y = y.replace('typedef uint32_t u32;', 'typedef uint32_t u32;\n__device__ unsigned long long* g_cyc = nullptr;\n'

@@ -41,8 +41,8 @@ if mode == "keep":
     for n, m in sizes:
         q, t, tab = setup(ctx, n, m)
         f = lambda: lib.slam_bf_knn2_u256(h, q.buf.ptr, n, t.buf.ptr, m, 0, tab.idx.ptr, tab.dist.ptr)
-        for bpc in (0, 8, 16, 32, 64):
-            ctx.set_tuning(blocks_per_cu=bpc, lead_rows=-1)
+        for bpc, queue in ((0, 1), (16, -1), (32, -1)):      # the queue plan; one block per chunk at 16 / 32 blocks per CU
+            ctx.set_tuning(blocks_per_cu=bpc, lead_rows=-1 if queue < 0 else 0, queue=queue)
             lib.slam_bf_reset_state(h)
             f()
             ctx.sync()
@@ -57,7 +57,7 @@ if mode == "keep":
             us = ctx.timer_stop() / reps * 1e3
             got = tab.download()
             same = np.array_equal(got[0], first[0]) and np.array_equal(got[1], first[1])
-            print(f"keep  {n}x{m} bpc={bpc:2d} {us:9.1f} us {n * m / us / 1e6:7.3f} Tpairs/s same={same}", flush=True)
+            print(f"keep  {n}x{m} queue={queue:2d} bpc={bpc:2d} {us:9.1f} us {n * m / us / 1e6:7.3f} Tpairs/s same={same}", flush=True)
         lib.slam_bf_reset_state(h)
         for o in (tab, q, t):
             o.free()

@@ -45,13 +45,15 @@ for it in range(iters):
                  tail=int(rng.choice([0, 0, -1, 1, 5, 64])), cold=int(rng.choice([0, 0, -1, 16, 48, 128, 1024])),
                  chunk=int(rng.choice([0, 0, 0, 32, 96, 256, 1024])))
     knobs["feed"] = int(rng.choice([0, -1, 1])) if knobs["R"] in (0, 1) else 0     # train rows through the LDS tile / SGPRs
+    # queue plans (resident workers drawing chunks by ticket): forced on a third of the searches that may take one
+    knobs["queue"] = int(rng.choice([0, 1, -1])) if knobs["R"] in (0, 1) and knobs["feed"] != -1 else int(rng.choice([0, -1]))
     ctx.set_tuning(**knobs)
     dq, dt = slamhip.DeviceDescriptors(ctx, q), slamhip.DeviceDescriptors(ctx, t)
     tab = slamhip.Top2Table(ctx, n)
     slamhip.knn2_device(ctx, dq.buf, n, dt.buf, m, tab.idx, tab.dist)
     gi, gd = tab.download()
     ei, ed = oracle.bf_knn_c(q, t, 2, threads=8)
-    ok = np.array_equal(gi, ei) and np.array_equal(gd, ed)
+    ok = np.array_equal(gi, ei) and np.array_equal(gd, ed) and ctx.state_dirty() == 0
     for o in (tab, dq, dt):
         o.free()
     if not ok:

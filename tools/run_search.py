@@ -1,5 +1,5 @@
 """Run the top-2 search NxM `reps` times on device-resident rows (a target for rocprofv3 passes on sizes other than
-the bench's; development aid).    python tools/run_search.py NxM [reps]"""
+the bench's; development aid).    python tools/run_search.py NxM [reps] [knob=value,...]   (knobs of Context.set_tuning)"""
 import os
 import sys
 
@@ -12,6 +12,8 @@ import slamhip  # noqa: E402
 n, m = (int(v) for v in sys.argv[1].split("x"))
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 ctx = slamhip.default_context()
+if len(sys.argv) > 3 and sys.argv[3]:
+    ctx.set_tuning(**{k: int(v) for k, v in (kv.split("=") for kv in sys.argv[3].split(","))})
 q = slamhip.DeviceDescriptors(ctx, np.random.default_rng(228).integers(0, 256, (n, 32), dtype=np.uint8))
 t = slamhip.DeviceDescriptors(ctx, np.random.default_rng(229).integers(0, 256, (m, 32), dtype=np.uint8))
 tab = slamhip.Top2Table(ctx, n)

@@ -1,7 +1,7 @@
 """Per-block timeline of one top-2 launch (development aid; needs the experiment build tools/exp/libslamhip_trace.so,
 which stamps wall_clock64() at block start / after the prologue / after the scan / at the end).
 
-    python tools/trace_probe.py NxM [lead_rows] [blocks_per_cu] [tail]        (0 = shipped choice, -1 = off)
+    python tools/trace_probe.py NxM [lead_rows] [blocks_per_cu] [tail] [queue]        (0 = shipped choice, -1 = off)
 
 Build the experiment library first: tools/build_exp.sh
 """
@@ -21,13 +21,15 @@ n, m = (int(v) for v in sys.argv[1].split("x"))
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else -1
 bpc = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 tail = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+queue = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 ctx = slamhip.Context(0)
 lib, h = ctx.lib, ctx.handle
 lib.slam_exp_set_trace.argtypes = [ctypes.c_void_p]
-ctx.set_tuning(blocks_per_cu=bpc, lead_rows=seed, tail=tail)
+ctx.set_tuning(blocks_per_cu=bpc, lead_rows=seed, tail=tail, queue=queue)
 plan = (ctypes.c_int32 * 10)()
 lib.slam_bf_plan_info(h, n, m, plan)
-blocks = plan[1] * plan[3]
+workers = slamhip.plan_describe(n, m, num_cu=plan[7], blocks_per_cu=bpc, lead_rows=seed, tail=tail, queue=queue)[0]["workers"]
+blocks = plan[1] * (workers or plan[3])           # a queue plan launches `workers` blocks per query block
 q = slamhip.DeviceDescriptors(ctx, np.random.default_rng(228).integers(0, 256, (n, 32), dtype=np.uint8))
 t = slamhip.DeviceDescriptors(ctx, np.random.default_rng(229).integers(0, 256, (m, 32), dtype=np.uint8))
 tab = slamhip.Top2Table(ctx, n)
@@ -45,10 +47,10 @@ TICK = 0.01   # wall_clock64 runs at 100 MHz: 10 ns per tick, in us
 t0 = tr[:, 0].min()
 start, pro, scan, end = ((tr[:, i] - t0) * TICK for i in range(4))
 span = end.max()
-print(f"{n}x{m} plan chunk={plan[2]} S={plan[3]} qblocks={plan[1]} blocks={blocks} seed={plan[4]}: event time {ms * 1e3:.1f} us, "
+print(f"{n}x{m} plan chunk={plan[2]} S={plan[3]} workers={workers} qblocks={plan[1]} blocks={blocks} seed={plan[4]}: event time {ms * 1e3:.1f} us, "
       f"first block start -> last block end {span:.1f} us")
 dur = end - start
-slots = plan[7] * 8
+slots = plan[7] * 6                                # resident blocks of the SGPR-fed kernel (6 waves per SIMD)
 print(f"block duration: mean {dur.mean():.1f} us, p5 {np.percentile(dur, 5):.1f}, p50 {np.percentile(dur, 50):.1f}, "
       f"p95 {np.percentile(dur, 95):.1f}, max {dur.max():.1f}; prologue mean {np.mean(pro - start):.2f} us, "
       f"scan mean {np.mean(scan - pro):.1f} us, epilogue mean {np.mean(end - scan):.2f} us (max {np.max(end - scan):.1f})")
@@ -60,6 +62,16 @@ for r in range(0, (blocks + slots - 1) // slots):
           f"mean duration {dur[sel].mean():7.1f}")
 bins = np.linspace(0, span, 41)
 act = [(np.minimum(end, b1) - np.maximum(start, b0)).clip(0).sum() / (b1 - b0) for b0, b1 in zip(bins[:-1], bins[1:])]
+if workers:
+    for name, v in (("start", start), ("prologue end", pro), ("wave 0 out of tickets", scan), ("block end", end)):
+        print(f"  {name:>22}: min {v.min():7.1f}  p5 {np.percentile(v, 5):7.1f}  p50 {np.percentile(v, 50):7.1f}  p95 {np.percentile(v, 95):7.1f}  max {v.max():7.1f} us")
+if workers:
+    qb = plan[1]
+    bxs, bys = order % qb, order // qb
+    per_q = np.array([scan[bxs == b].max() for b in range(qb)])       # when the queue of a query block ran dry
+    print(f"  queue of a query block runs dry: min {per_q.min():.1f} p50 {np.median(per_q):.1f} max {per_q.max():.1f} us; "
+          f"by (query block mod 8): " + " ".join(f"{per_q[np.arange(qb) % 8 == x].mean():.1f}" for x in range(8)))
+    print("  wave 0 out of tickets, mean by worker index: " + " ".join(f"{scan[bys == k].mean():.1f}" for k in range(0, workers, max(1, workers // 12))))
 print("active blocks per 1/40 of the span:", " ".join(f"{a:.0f}" for a in act))
 full = np.array(act) >= 0.97 * min(slots, blocks)
 print(f"time below 97 % of full residency: head {bins[1:][full][0] - bins[1] if full.any() else span:.1f} us, "
