@@ -157,9 +157,13 @@ SLAM_API int slam_bf_knn2_u256_host(slam_ctx* ctx, const uint8_t* h_query, int64
  *   [8] queue         1 = a queue plan: as many worker blocks per query block as are resident at once, whose waves draw
  *                     the chunks by ticket and keep their top-2 from chunk to chunk; -1 = one block per chunk (the plans
  *                     above).  Shipped: a queue plan for train sets of at least 16384 rows when every query block gets at
- *                     least two workers and they fill at least 80 % of the resident slots; then [7] forces the rows of a
- *                     uniform chunk, [4] > 0 the shortest chunk at the end of the queue, [4] = -1 no shrinking chunks */
-#define SLAM_BF_KNOBS 9
+ *                     least two workers with at least 1024 rows apiece and they fill at least 80 % of the resident slots; then [7] forces the rows of a
+ *                     uniform chunk, [4] > 0 the shortest chunk at the end of the queue, [4] = -1 no shrinking chunks
+ *   [9] merge         how the workers of a queue plan exchange what they know: 1 = by merging their best two rows into the
+ *                     per-query slot and reading its 2nd row back (the exact 2nd-best distance of everything folded in so
+ *                     far), -1 = through a per-query bound (the minimum of the workers' own 2nd-best distances, as the
+ *                     one-block-per-chunk plans do).  Shipped: merging from 12 workers per query block up */
+#define SLAM_BF_KNOBS 10
 SLAM_API int slam_bf_set_tuning(slam_ctx* ctx, const int32_t* h_knobs, int count);
 /* The launch plan slam_bf_knn2_u256 would use for N x M on this context: h_plan int32 [10] =
  * {R, query blocks, uniform chunk rows, chunks, leader rows, leader chunks, shrinking tail chunks, CUs,
@@ -169,7 +173,7 @@ SLAM_API int slam_bf_plan_info(slam_ctx* ctx, int64_t N, int64_t M, int32_t* h_p
  * and the shape, so that the planner can be held to its invariants on a host without a GPU.  h_plan int32 [14] =
  * slam_bf_plan_info's ten entries (h_plan[7] = num_cu) + {table-free: the kernel computes its chunk from the block index
  * and no boundary table is uploaded, bound-free: no block reads or writes a bound, workers: worker blocks per query block
- * of a queue plan (knob [8]; 0 = one block per chunk), resident: blocks per CU the planner counts on for that}.  The chunk boundary table (chunks + 1
+ * of a queue plan (knob [8]; 0 = one block per chunk), resident: blocks per CU the planner counts on for that, + 256 when the workers exchange by merging (knob [9])}.  The chunk boundary table (chunks + 1
  * ascending row indices from 0 to M) goes to h_tbl (up to tbl_cap entries; may be NULL) and its length to *tbl_len.
  * rows_on_host: the train rows lie in pinned host memory (frame-sized host calls).  qb_all: the query blocks of all the
  * searches that share the launch (slam_bf_knn2_batch_u256), 0 for a search that has the grid to itself. */

@@ -254,6 +254,40 @@ __device__ __forceinline__ void share_bound(u32* __restrict__ bound, int qbase, 
     }
 }
 
+// The exchange as a MERGE (round 4): instead of publishing its own 2nd-best distance, a lane whose pair (b1, b2) changed since
+// it last did so folds the pair into best[q] - the two atomic minima of the final merge (see the epilogue) - and takes the
+// slot's 2nd key as the bound: the exact 2nd-best distance over EVERYTHING the blocks of this query have folded in so far,
+// where the minimum of their own 2nd-best distances is that of a set k times smaller (k blocks that have scanned s rows each:
+// the quantile 2 / (k s) instead of about sqrt(1.4 / k) / s - at k = 48, the 1/8 shard's workers, what the old bound reaches
+// after 4 s rows).  Folding a pair twice is harmless: keys are distinct rows, a lane that meets its own 1st key in the slot
+// (o1 == b1) pushes no loser, and every push is a real key other than the smallest one.  A lane whose pair did not change
+// reads the 2nd key with a relaxed agent-scope load, as it read the bound before.
+// sent[r]: the lane's b2 at its last fold (b2 changes whenever the pair does: a new key either becomes b2 or moves b1 there).
+template <int R>
+__device__ __forceinline__ void share_union(unsigned long long* __restrict__ best, int qbase, int N, const u32 (&b1)[R],
+                                            const u32 (&b2)[R], u32 (&init)[R], u32 (&gk)[R], u32 (&sent)[R]) {
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int qi = qbase + r * 64;
+        if (qi < N) {
+            u32* half = (u32*)&best[qi];                          // little endian: [0] = 2nd key, [1] = 1st key
+            u32 k2;
+            if (b2[r] != sent[r]) {
+                const u32 o1 = atomicMin(half + 1, b1[r]);
+                const u32 loser = o1 == b1[r] ? SLAM_KEY_NONE : max(o1, b1[r]);
+                const u32 push = min(loser, b2[r]);                // b2 != sent implies b2 != none: there is something to push
+                k2 = min(atomicMin(half, push), push);
+                sent[r] = b2[r];
+            } else {
+                k2 = __hip_atomic_load(half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            const u32 g = k2 >> SLAM_KEY_IDX_BITS;                 // 511 while the slot holds fewer than two keys
+            gk[r] = g;
+            init[r] = SLAM_ACC_BIAS - min(b2[r] >> SLAM_KEY_IDX_BITS, g + 1);
+        }
+    }
+}
+
 // Per-query merge state shared by the blocks of one launch (device memory owned by the ctx).
 // Invariant between launches: best[] = ~0, bound[] = 0x7F7F7F7F, arrivals[] = 0, cursor[] = 0; the last block
 // of every query block restores it after decoding, so no memset or merge kernel runs per call.
@@ -281,7 +315,7 @@ __device__ __forceinline__ void bf_top2_block(const uint4* __restrict__ q, int N
                                               const int* __restrict__ tbl, int lead, bf_state st, int train_base,
                                               int2* __restrict__ out_idx, int2* __restrict__ out_dist,
                                               uint4* __restrict__ keep, const int bx, const int by, const int S,
-                                              const int cold_arg, const int uni_arg, const int M, const int nchunks) {
+                                              const int cold_arg, const int uni_arg, const int M, const int nchunks, const int merge_arg) {
     // QUEUE is a template parameter, not a run-time flag: with both forms in one kernel the one-block-per-chunk plans ran
     // 1-2.5 % slower than without the queue code (30 SGPR spills instead of 3; profiles/r04_ab_queue.log).  A queue plan has
     // a boundary table, exchanges bounds and has no leaders.
@@ -289,7 +323,6 @@ __device__ __forceinline__ void bf_top2_block(const uint4* __restrict__ q, int N
     const int uni = QUEUE ? 0 : uni_arg;
     __shared__ uint4 tile[2][SLAM_TILE_ROWS * 2 + 4];
     __shared__ u32 s_last;
-    u32* __restrict__ bound = st.bound;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int qbase = bx * (256 * R) + wave * (64 * R) + lane;
@@ -315,22 +348,30 @@ __device__ __forceinline__ void bf_top2_block(const uint4* __restrict__ q, int N
         qr[r][0] = a.x; qr[r][1] = a.y; qr[r][2] = a.z; qr[r][3] = a.w;
         qr[r][4] = b.x; qr[r][5] = b.y; qr[r][6] = b.z; qr[r][7] = b.w;
     }
-    u32 b1[R], b2[R], init[R], gk[R], pend[R];
+    // How the blocks of a query exchange what they know: as a bound (share_bound) or as a merge (share_union; queue plans
+    // with many workers per query block - a wave-uniform run-time choice inside the queue kernel only).
+    const bool merging = QUEUE && merge_arg != 0;
+    const u32 nobody = merging ? (SLAM_KEY_NONE >> SLAM_KEY_IDX_BITS) : SLAM_BOUND_IDLE;   // what gk reads while nothing is published
+    u32 b1[R], b2[R], init[R], gk[R], pend[R];                     // pend: parked atomic returns (bound form) / b2 at the last fold (merge form)
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        pend[r] = 0u;
+        pend[r] = merging ? SLAM_KEY_NONE : 0u;
         b1[r] = SLAM_KEY_NONE;
         b2[r] = SLAM_KEY_NONE;
         init[r] = SLAM_ACC_BIAS - (SLAM_KEY_NONE >> SLAM_KEY_IDX_BITS);  // "distance 511": everything enters
-        gk[r] = SLAM_BOUND_IDLE;
+        gk[r] = nobody;
     }
+    auto share = [&]() {
+        if (merging) share_union<R>(st.best, qbase, N, b1, b2, init, gk, pend);
+        else share_bound<R>(st.bound, qbase, N, b2, init, gk, pend);
+    };
     // A chunk starts COLD when nobody has published a bound for any of the wave's queries yet (the first dispatch round,
     // every block of a frame-sized search): its first `cold` rows are then folded in without a filter (insert_rows).
     // Blocks of later rounds pick up a bound at their first exchange and go straight to the filtered scan.
     auto nobody_published = [&]() -> bool {
         bool any = false;
 #pragma unroll
-        for (int r = 0; r < R; r++) any = any || gk[r] != SLAM_BOUND_IDLE;
+        for (int r = 0; r < R; r++) any = any || gk[r] != nobody;
         return __ballot(any) == 0ull;
     };
     auto tighten = [&]() {
@@ -406,12 +447,12 @@ __device__ __forceinline__ void bf_top2_block(const uint4* __restrict__ q, int N
             };
 #if SLAM_EXP_QLOOP == 3
             u32 warm = touch(c0);
-            if (!nobound) share_bound<R>(bound, qbase, N, b2, init, gk, pend);
+            if (!nobound) share();
             asm volatile("" ::"v"(warm));                  // the chunk's first lines are there
 #else
             u32 warm = 0;
             if (!queue) warm = touch(c0);
-            if (!nobound) share_bound<R>(bound, qbase, N, b2, init, gk, pend);
+            if (!nobound) share();
             if (queue) {
                 ci = __builtin_amdgcn_readfirstlane(ticket);
                 if (ci >= nchunks) break;
@@ -429,7 +470,7 @@ __device__ __forceinline__ void bf_top2_block(const uint4* __restrict__ q, int N
             bool is_cold = fresh && cold >= 16 && (nobound || nobody_published());
             bool shared = true;                            // the exchange in front of the chunk's first stretch is done
             while (row < c1) {
-                if (!shared && !nobound) share_bound<R>(bound, qbase, N, b2, init, gk, pend);
+                if (!shared && !nobound) share();
                 shared = false;
                 const int done = row - c0;
                 is_cold = is_cold && done == 0;
@@ -488,7 +529,7 @@ __device__ __forceinline__ void bf_top2_block(const uint4* __restrict__ q, int N
                     nxt[i] = g < 2 * t1 ? t[(size_t)g] : make_uint4(0, 0, 0, 0);
                 }
             }
-            if (!nobound) share_bound<R>(bound, qbase, N, b2, init, gk, pend);
+            if (!nobound) share();
             const int cnt = __builtin_amdgcn_readfirstlane(min(SLAM_TILE_ROWS, t1 - tb));
             const uint4* tp = tile[buf];
             // software pipeline: the next row is read from LDS while the current one is computed (the last
@@ -533,7 +574,7 @@ __device__ __forceinline__ void bf_top2_block(const uint4* __restrict__ q, int N
                     insert_rows<R, U>(acc, (u32)(tb + j), b1, b2);
                 }
                 tighten();
-                if (j < cnt && !nobound) share_bound<R>(bound, qbase, N, b2, init, gk, pend);
+                if (j < cnt && !nobound) share();
                 while (seg_end <= j) seg_end *= 2;
             }
             while (true) {
@@ -544,7 +585,7 @@ __device__ __forceinline__ void bf_top2_block(const uint4* __restrict__ q, int N
                     filter_update<R, U>(acc, (u32)(tb + j), b1, b2, init);
                 }
                 if (lim >= cnt) break;
-                if (!nobound) share_bound<R>(bound, qbase, N, b2, init, gk, pend);
+                if (!nobound) share();
                 seg_end *= 2;
             }
             for (; j < cnt; j++) {
@@ -574,6 +615,26 @@ __device__ __forceinline__ void bf_top2_block(const uint4* __restrict__ q, int N
     // load plus one round trip per lost race (epilogue of a 4096 x 4096 block: 6.6 us mean, profiles/r02_block_timeline.log).
     // gk >= the final 2nd-best distance (share_bound): a block whose best row is farther than that cannot contribute and
     // skips the atomics without looking (rows AT that distance may still win the tie on index).
+    if (merging) {
+    // (merge form of the exchange: a lane whose pair has not changed since its last fold has nothing left to merge)
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int qi = qbase + r * 64;
+        if (qi < N && b1[r] != SLAM_KEY_NONE && (b1[r] >> SLAM_KEY_IDX_BITS) <= gk[r] &&
+            (b2[r] != pend[r] || b2[r] == SLAM_KEY_NONE)) {       // (a lone row: b2 is none, and so was it at the last fold)
+            u32* half = (u32*)&st.best[qi];
+            const u32 o1 = atomicMin(half + 1, b1[r]);
+            const u32 loser = o1 == b1[r] ? SLAM_KEY_NONE : max(o1, b1[r]);
+            const u32 push = min(loser, b2[r]);
+            if (push != SLAM_KEY_NONE) {
+                // returning form on purpose: "the value is back" means the minimum has been taken at the memory side, which is
+                // what the arrival ticket below relies on (a no-return atomic is only known to have been sent)
+                const u32 o2 = atomicMin(half, push);
+                asm volatile("" ::"v"(o2));
+            }
+        }
+    }
+    } else {
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const int qi = qbase + r * 64;
@@ -597,6 +658,7 @@ __device__ __forceinline__ void bf_top2_block(const uint4* __restrict__ q, int N
             }
         }
     }
+    }
     // Arrival ticket.  Everything a block contributes travels in agent-scope atomics that RETURN (the two minima above):
     // they are executed at the memory side (MI355X_MICROARCH.md, "Global float atomics": never in an XCD's L2, nothing stays
     // dirty in L2), and a returned value means the operation is done there.  So: every wave waits for its returns, block
@@ -607,8 +669,10 @@ __device__ __forceinline__ void bf_top2_block(const uint4* __restrict__ q, int N
     // 2000 x 2000 10.7 -> 9.4 us, the 1/8 shard 159.9 -> 154.8 us without it (profiles/r03_ab_cold_start.log; the guide
     // lists "agent atomics both sides" among the valid forms).  Placement-independent: nothing relies on which XCD a block
     // runs on.
+    if (!merging) {
 #pragma unroll
-    for (int r = 0; r < R; r++) asm volatile("" ::"v"(pend[r]));   // the parked returns of share_bound
+        for (int r = 0; r < R; r++) asm volatile("" ::"v"(pend[r]));   // the parked returns of share_bound
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
@@ -636,7 +700,7 @@ __device__ __forceinline__ void bf_top2_block(const uint4* __restrict__ q, int N
             out_dist[qi] = od;
             // restore the between-launch invariant for these queries (all other blocks are done with them)
             __hip_atomic_store(&st.best[qi], ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&st.bound[qi], SLAM_BOUND_IDLE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!merging) __hip_atomic_store(&st.bound[qi], SLAM_BOUND_IDLE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     if (tid == 0) __hip_atomic_store(&st.arrivals[bx], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -650,7 +714,7 @@ __global__ __launch_bounds__(256) void bf_top2_kernel(const uint4* __restrict__ 
                                                       int lead, bf_state st, int train_base,
                                                       int2* __restrict__ out_idx, int2* __restrict__ out_dist,
                                                       uint4* __restrict__ keep, int cold, int uni, int M,
-                                                      int nchunks) {
+                                                      int nchunks, int merge) {
     // Queue plans rotate the query blocks from one row of workers to the next: worker y of query block x is block
     // ((x - y) mod grid.x, y).  Blocks go to the XCDs round robin by their linear index, so without the rotation ALL workers
     // of a query block sit on one XCD (grid.x is a multiple of 8 for the big grids) - and the XCDs do not run at the same
@@ -662,7 +726,7 @@ __global__ __launch_bounds__(256) void bf_top2_kernel(const uint4* __restrict__ 
     int bx = (int)blockIdx.x;
     if (QUEUE) bx = (bx + (int)blockIdx.y) % (int)gridDim.x;
     bf_top2_block<R, SFEED, QUEUE>(q, N, t, tbl, lead, st, train_base, out_idx, out_dist, keep, bx, (int)blockIdx.y,
-                            (int)gridDim.y, cold, uni, M, nchunks);
+                            (int)gridDim.y, cold, uni, M, nchunks, merge);
 }
 
 // ---- several independent searches in ONE launch -------------------------------------------------------------------
@@ -690,10 +754,10 @@ __global__ __launch_bounds__(256) void bf_top2_batch_kernel(const bf_batch b) {
     const int bx = local % p.qblocks, by = local / p.qblocks;
     if (p.sfeed)   // block-uniform: the search's train rows travel through SGPRs (short or long chunks in device memory)
         bf_top2_block<1, true, false>(p.q, p.N, p.t, p.tbl, p.lead, p.st, p.train_base, p.out_idx, p.out_dist, p.keep, bx, by, p.S, p.cold,
-                               p.uni, p.M, 0);
+                               p.uni, p.M, 0, 0);
     else
         bf_top2_block<1, false, false>(p.q, p.N, p.t, p.tbl, p.lead, p.st, p.train_base, p.out_idx, p.out_dist, p.keep, bx, by, p.S, p.cold,
-                                p.uni, p.M, 0);
+                                p.uni, p.M, 0, 0);
 }
 
 // merge G decoded tables by (dist, idx)
@@ -743,6 +807,7 @@ struct bf_plan {
     int sfeed;       // 1: train rows through SGPRs (bf_scan_sgpr.h), 0: through an LDS tile
     int cold;        // rows a chunk that starts without any bound folds in unfiltered (a multiple of 16; 0 = none)
     int uni;         // > 0: every chunk has this many rows (no leaders, no tail) and the kernel needs no boundary table
+    int merge;       // queue plans: 1 = the workers exchange by MERGING their pairs into best[] (share_union), 0 = through bound[]
     int workers;     // > 0: a QUEUE plan - grid.y = this many worker blocks per query block, whose waves draw the S chunks
                      // of the table by ticket (bf_top2_block); 0: one block per chunk, grid.y = S
 };
@@ -759,6 +824,7 @@ static int bf_check_knobs(const int* k) {
     SLAM_REQUIRE(k[7] >= 0 && k[7] <= (1 << 22) && k[7] % 32 == 0, "chunk must be a multiple of 32 rows");
     SLAM_REQUIRE(k[8] >= -1 && k[8] <= 1, "queue must be 0 (heuristic), 1 (workers draw chunks by ticket) or -1 (one block per chunk)");
     SLAM_REQUIRE(!(k[8] == 1 && (k[0] > 1 || k[5] == -1)), "a queue plan runs the SGPR-fed scan at one query per lane");
+    SLAM_REQUIRE(k[9] >= -1 && k[9] <= 1, "merge must be 0 (heuristic), 1 (queue workers exchange by merging) or -1 (through bounds)");
     return SLAM_OK;
 }
 
@@ -939,6 +1005,7 @@ static bf_plan make_plan_core(int num_cu, const int* k, int64_t N, int64_t M, st
     // one round and no chunk longer than the unfiltered start: the kernel exchanges no bounds at all (passed as -cold)
     if (qb_launch * (int64_t)p.S <= slots && p.chunk <= p.cold && p.lead == 0) p.cold = -p.cold;   // (S: the tail's extra chunks counted)
     p.workers = 0;
+    p.merge = 0;
     // ---- queue plan (round 4): as many worker blocks per query block as are resident at once; their waves draw the chunks
     // of the table by ticket and keep their top-2 from chunk to chunk (bf_top2_block).  What it removes is what made the
     // 1/8 query shard of an 8-GPU run 27 % less efficient than the full grid: 137 starts without a
@@ -950,7 +1017,7 @@ static bf_plan make_plan_core(int num_cu, const int* k, int64_t N, int64_t M, st
     const int64_t resident = (int64_t)num_cu * SLAM_BF_RESIDENT;
     const int64_t W = resident / p.qblocks > 1 ? resident / p.qblocks : 1;   // (forced on a grid of many dispatch rounds: one)
     const bool can_queue = p.R == 1 && k[5] != -1 && !rows_on_host && qb_all <= p.qblocks && (M >= 16384 || k[8] == 1) && W >= 1;
-    const bool want_queue = k[8] == 1 || (k[8] == 0 && W >= 2 && W * p.qblocks * 10 >= resident * 8 && M >= 512 * W);
+    const bool want_queue = k[8] == 1 || (k[8] == 0 && W >= 2 && W * p.qblocks * 10 >= resident * 8 && M >= 1024 * W);
     if (can_queue && want_queue) {
         int64_t c = k[7] ? k[7] : 256;
         const int64_t c_floor = (M / 3000 + 255) / 256 * 256;               // keeps the table within one ring slot
@@ -974,6 +1041,9 @@ static bf_plan make_plan_core(int num_cu, const int* k, int64_t N, int64_t M, st
         p.lead = 0; p.lead_rows = 0; p.tail = shrinking; p.uni = 0; p.sfeed = 1;
         p.cold = k[6] < 0 ? 0 : (k[6] ? k[6] : SLAM_COLD_ROWS);
         p.workers = (int)(W < p.S ? W : p.S);
+        // the exact bound of a merge pays where many workers share a query (48 on the 1/8 shard: 148.5 -> 145.3 us; 24: 273 ->
+        // 266; six at 64k x 64k: 1015 -> 1022, where the minimum of six 2nd-best distances is nearly as good and costs less)
+        p.merge = k[9] == 1 || (k[9] == 0 && p.workers >= 12) ? 1 : 0;
     }
     return p;
 }
@@ -1004,7 +1074,7 @@ extern "C" int slam_bf_plan_describe(int num_cu, const int32_t* h_knobs, int cou
     h_plan[0] = p.R; h_plan[1] = p.qblocks; h_plan[2] = p.chunk; h_plan[3] = p.S;
     h_plan[4] = p.lead_rows; h_plan[5] = p.lead; h_plan[6] = p.tail; h_plan[7] = num_cu;
     h_plan[8] = p.sfeed; h_plan[9] = p.cold < 0 ? -p.cold : p.cold; h_plan[10] = p.uni ? 1 : 0; h_plan[11] = p.cold < 0 ? 1 : 0;
-    h_plan[12] = p.workers; h_plan[13] = SLAM_BF_RESIDENT;
+    h_plan[12] = p.workers; h_plan[13] = SLAM_BF_RESIDENT | (p.merge << 8);
     *tbl_len = (int64_t)tbl.size();
     for (int64_t i = 0; i < (int64_t)tbl.size() && i < tbl_cap; i++) h_tbl[i] = tbl[(size_t)i];
     return SLAM_OK;
@@ -1199,7 +1269,7 @@ static int bf_pass(slam_ctx* ctx, const void* d_query, int64_t N, const void* d_
     SLAM_HIP(hipGetLastError());
     if (int rc = slam_prof_begin(ctx)) return rc;
 #define SLAM_BF_LAUNCH(R_, F_, Q_) \
-    bf_top2_kernel<R_, F_, Q_><<<grid, block, 0, ctx->stream>>>(q, (int)N, t, d_tbl, p.lead, st, tb, oi, od, (uint4*)d_keep, p.cold, p.uni, (int)M, nchunks)
+    bf_top2_kernel<R_, F_, Q_><<<grid, block, 0, ctx->stream>>>(q, (int)N, t, d_tbl, p.lead, st, tb, oi, od, (uint4*)d_keep, p.cold, p.uni, (int)M, nchunks, p.merge)
     switch (p.R) {
         case 8: SLAM_BF_LAUNCH(8, false, false); break;
         case 4: SLAM_BF_LAUNCH(4, false, false); break;

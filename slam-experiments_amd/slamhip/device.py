@@ -79,10 +79,10 @@ class Context:
         return self.malloc(host.nbytes).upload(host)
 
     def set_tuning(self, R: int = 0, blocks_per_cu: int = 0, lead_rows: int = 0, lead_chunk: int = 0,
-                   tail: int = 0, feed: int = 0, cold: int = 0, chunk: int = 0, queue: int = 0) -> None:
+                   tail: int = 0, feed: int = 0, cold: int = 0, chunk: int = 0, queue: int = 0, merge: int = 0) -> None:
         """Experiment knobs of the top-2 search on this context (``slam_bf_set_tuning``); no arguments = shipped plan."""
-        knobs = (ctypes.c_int32 * 9)(R, blocks_per_cu, lead_rows, lead_chunk, tail, feed, cold, chunk, queue)
-        check(self.lib.slam_bf_set_tuning(self.handle, knobs, 9))
+        knobs = (ctypes.c_int32 * 10)(R, blocks_per_cu, lead_rows, lead_chunk, tail, feed, cold, chunk, queue, merge)
+        check(self.lib.slam_bf_set_tuning(self.handle, knobs, 10))
 
     def state_dirty(self) -> int:
         """Words of the search's merge state that are not idle once the stream has drained (``slam_bf_state_dirty``):
@@ -131,7 +131,7 @@ def default_context() -> Context:
         return _default_ctx
 
 
-PLAN_KNOBS = ("R", "blocks_per_cu", "lead_rows", "lead_chunk", "tail", "feed", "cold", "chunk", "queue")
+PLAN_KNOBS = ("R", "blocks_per_cu", "lead_rows", "lead_chunk", "tail", "feed", "cold", "chunk", "queue", "merge")
 
 
 def plan_describe(n: int, m: int, num_cu: int = 256, qb_all: int = 0, rows_on_host: bool = False, **knobs):
@@ -149,4 +149,6 @@ def plan_describe(n: int, m: int, num_cu: int = 256, qb_all: int = 0, rows_on_ho
     check(lib.slam_bf_plan_describe(num_cu, k, len(PLAN_KNOBS), n, m, qb_all, int(rows_on_host), plan, tbl, cap, ctypes.byref(length)))
     names = ("R", "qblocks", "chunk", "chunks", "lead_rows", "lead_chunks", "tail_chunks", "cus", "sgpr_feed", "cold_rows",
              "table_free", "bound_free", "workers", "resident")
-    return dict(zip(names, plan)), list(tbl[:min(length.value, cap)])
+    out = dict(zip(names, plan))
+    out["merge"], out["resident"] = out["resident"] >> 8, out["resident"] & 255
+    return out, list(tbl[:min(length.value, cap)])

@@ -29,7 +29,7 @@ def test_status_codes_and_messages(gpu_ctx):
     assert lib.slam_bf_set_tuning(ctx.handle, knobs(3), 1) == -1                       # R not in {1, 2, 4, 8}
     assert lib.slam_bf_set_tuning(None, knobs(1), 1) == -1 and lib.slam_bf_set_tuning(ctx.handle, knobs(1, 0, -2), 3) == -1
     assert lib.slam_bf_set_tuning(ctx.handle, knobs(1, 0, 64, 48), 4) == -1            # leader chunk not a multiple of 32
-    assert lib.slam_bf_set_tuning(ctx.handle, None, 3) == -1 and lib.slam_bf_set_tuning(ctx.handle, knobs(*[0] * 9), 9) == -1
+    assert lib.slam_bf_set_tuning(ctx.handle, None, 3) == -1 and lib.slam_bf_set_tuning(ctx.handle, knobs(*[0] * 11), 11) == -1
     assert lib.slam_bf_set_tuning(ctx.handle, knobs(2, 0, 0, 0, 0, 1), 6) == -1        # the SGPR feed holds one query per lane
     assert lib.slam_bf_set_tuning(ctx.handle, knobs(1, 0, 0, 0, 0, 2), 6) == -1        # feed not in {-1, 0, 1}
     assert lib.slam_bf_set_tuning(ctx.handle, None, 0) == 0                            # reset to the shipped plan

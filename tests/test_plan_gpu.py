@@ -45,13 +45,15 @@ def test_every_plan_shape_is_bit_identical(gpu_ctx, n, m):
         assert ctx.state_dirty() == 0
         # queue plans (round 4): resident workers whose waves draw the chunks by ticket - any uniform chunk, shortest chunk
         # and unfiltered start; with and without the shrinking end of the queue
+        # and both ways of exchanging what the workers know (a per-query bound / merging their pairs into the result slot)
         for chunk in (0, 32, 64, 512):
             for tail in (0, -1, 16, 48):
                 for cold in (0, -1, 16, 1024):
-                    ctx.set_tuning(queue=1, chunk=chunk, tail=tail, cold=cold)
-                    idx, dist = _search(ctx, dq, n, dt, m, tab)
-                    assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist), ("queue", chunk, tail, cold)
-                    assert ctx.state_dirty() == 0, ("queue", chunk, tail, cold)
+                    for merge in (1, -1):
+                        ctx.set_tuning(queue=1, chunk=chunk, tail=tail, cold=cold, merge=merge)
+                        idx, dist = _search(ctx, dq, n, dt, m, tab)
+                        assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist), ("queue", chunk, tail, cold, merge)
+                        assert ctx.state_dirty() == 0, ("queue", chunk, tail, cold, merge)
     finally:
         ctx.set_tuning()
         for o in (tab, dq, dt):
@@ -184,12 +186,13 @@ def test_queue_plan_is_what_large_searches_run_and_it_leaves_the_state_idle(gpu_
     tab = slamhip.Top2Table(ctx, n)
     try:
         got = {}
-        for queue in (0, -1, 1):
-            ctx.set_tuning(queue=queue)
-            got[queue] = _search(ctx, dq, n, dt, m, tab)
-            assert ctx.state_dirty() == 0, queue
-        for queue in (-1, 1):
-            assert np.array_equal(got[0][0], got[queue][0]) and np.array_equal(got[0][1], got[queue][1]), queue
+        for queue, merge in ((0, 0), (-1, 0), (1, 1), (1, -1)):
+            ctx.set_tuning(queue=queue, merge=merge)
+            got[queue, merge] = _search(ctx, dq, n, dt, m, tab)
+            assert ctx.state_dirty() == 0, (queue, merge)
+        for key in got:
+            assert np.array_equal(got[0, 0][0], got[key][0]) and np.array_equal(got[0, 0][1], got[key][1]), key
+        got = {0: got[0, 0]}
         rows = np.r_[np.arange(80), rng.choice(n, 300, replace=False)]
         ridx, rdist = oracle.bf_knn_c(q[rows], t, 2, threads=8)
         assert np.array_equal(got[0][0][rows], ridx) and np.array_equal(got[0][1][rows], rdist)

@@ -50,8 +50,8 @@ class Lib:
         self.ctx = ctypes.c_void_p()
         assert self.lib.slam_ctx_create(0, ctypes.byref(self.ctx)) == 0, self.lib.slam_last_error()
         if knobs:
-            names = ("R", "bpc", "lead", "leadchunk", "tail", "feed", "cold", "chunk", "queue")
-            nk = 9 if "queue" in knobs else (8 if ("cold" in knobs or "chunk" in knobs) else 6)      # older builds know six / eight knobs
+            names = ("R", "bpc", "lead", "leadchunk", "tail", "feed", "cold", "chunk", "queue", "merge")
+            nk = 10 if "merge" in knobs else 9 if "queue" in knobs else (8 if ("cold" in knobs or "chunk" in knobs) else 6)      # older builds know six / eight knobs
             k = (ctypes.c_int32 * nk)(*(knobs.get(n, 0) for n in names[:nk]))
             assert self.lib.slam_bf_set_tuning(self.ctx, k, nk) == 0, self.lib.slam_last_error()
 

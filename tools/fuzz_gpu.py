@@ -47,6 +47,7 @@ for it in range(iters):
     knobs["feed"] = int(rng.choice([0, -1, 1])) if knobs["R"] in (0, 1) else 0     # train rows through the LDS tile / SGPRs
     # queue plans (resident workers drawing chunks by ticket): forced on a third of the searches that may take one
     knobs["queue"] = int(rng.choice([0, 1, -1])) if knobs["R"] in (0, 1) and knobs["feed"] != -1 else int(rng.choice([0, -1]))
+    knobs["merge"] = int(rng.choice([0, 1, -1]))          # how the workers of a queue plan exchange what they know
     ctx.set_tuning(**knobs)
     dq, dt = slamhip.DeviceDescriptors(ctx, q), slamhip.DeviceDescriptors(ctx, t)
     tab = slamhip.Top2Table(ctx, n)

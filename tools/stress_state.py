@@ -37,7 +37,7 @@ for it in range(iters):
     if it % 3 == 0:                                  # planted near-duplicates: tight bounds, ties on the index
         rows = rng.integers(0, m, min(n, 64))
         t[rows] = q[rng.integers(0, n, len(rows))]
-    ctx.set_tuning(queue=(0, 0, 1, 0, 0, -1)[it % 6])
+    ctx.set_tuning(queue=(0, 0, 1, 0, 0, -1)[it % 6], merge=(0, 1, -1, 0)[it % 4])
     gi, gd = slamhip.knn_match_arrays(q, t, 2, ctx=ctx)
     dirty = ctx.state_dirty()
     if dirty:
