@@ -659,16 +659,27 @@ __device__ __forceinline__ void bf_top2_block(const uint4* __restrict__ q, int N
         }
     }
     }
-    // Arrival ticket.  Everything a block contributes travels in agent-scope atomics that RETURN (the two minima above):
-    // they are executed at the memory side (MI355X_MICROARCH.md, "Global float atomics": never in an XCD's L2, nothing stays
-    // dirty in L2), and a returned value means the operation is done there.  So: every wave waits for its returns, block
-    // barrier, one relaxed ticket; the block that draws the last ticket reads the slots back with agent-scope loads (L1 is
-    // bypassed; the acquire in front of them is kept as cheap insurance - it runs once per query block).  The G16 counter
-    // form has an agent-scope RELEASE fence (buffer_wbl2 sc1) in front of the ticket; it writes back dirty L2 lines, of
-    // which this hand-off has none, and cost 1.7 us on the critical path of every block: 4096 x 4096 18.4 -> 16.7 us,
-    // 2000 x 2000 10.7 -> 9.4 us, the 1/8 shard 159.9 -> 154.8 us without it (profiles/r03_ab_cold_start.log; the guide
-    // lists "agent atomics both sides" among the valid forms).  Placement-independent: nothing relies on which XCD a block
-    // runs on.
+    // Arrival ticket.  Everything a block contributes travels in agent-scope INTEGER atomics in the RETURNING form
+    // (global_atomic_umin ... sc0: the merges above, every write to bound[] in share_bound / share_union), and what is relied
+    // on is this, no more:
+    //   (1) a returned value means the read-modify-write has been performed at the point all XCDs share - an agent-scope
+    //       atomic is never satisfied from an XCD's own L2 (the guide measures that for float atomics, "Global float atomics";
+    //       for the integer minima used here it is what 140 000 + 46 000 fuzzed searches and the state soaks of rounds 3 / 4
+    //       show, and what makes cross-XCD merges come out right at all), and nothing of it stays dirty in an L2;
+    //   (2) every wave waits for all its returns (s_waitcnt vmcnt(0): vector-memory operations return in issue order), then
+    //       the block barrier, then ONE lane's relaxed agent-scope ticket - the guide's hand-off table, first row: "an
+    //       agent-scope atomic add ... after every storing wave's vmcnt(0) wait ... the workgroup whose add came last, told by
+    //       the value its add returned";
+    //   (3) the block that draws the last ticket invalidates its L1 (agent acquire, kept as cheap insurance: it runs once per
+    //       query block), passes a barrier and reads the slots with sc1 loads ("loads, all sc1" in that table; the payload
+    //       being atomics rather than sc1 stores is the guide's "{8-B agent atomics both sides}" form).
+    // The G16 counter recipe has an agent-scope RELEASE fence (buffer_wbl2 sc1) in front of the ticket; it writes back dirty L2
+    // lines, of which this hand-off has none, and cost 1.7 us on the critical path of every block: 4096 x 4096 18.4 -> 16.7 us,
+    // 2000 x 2000 10.7 -> 9.4 us, the 1/8 shard 159.9 -> 154.8 us without it (profiles/r03_ab_cold_start.log).
+    // tests/test_isa_handoff_cpu.py holds every build to (1)-(3) on the disassembly (return forms, wait and barrier in front
+    // of the ticket, invalidate + sc1 loads behind it; profiles/r04_isa_handoff_excerpt.txt), and every search leaves the
+    // whole state idle, which the GPU tests assert on the state itself (slam_bf_state_dirty).  Placement-independent: nothing
+    // relies on which XCD a block runs on.
     if (!merging) {
 #pragma unroll
         for (int r = 0; r < R; r++) asm volatile("" ::"v"(pend[r]));   // the parked returns of share_bound

@@ -1,0 +1,119 @@
+"""CPU suite: the cross-workgroup hand-off of the top-2 search, pinned on the gfx950 ISA of the built library.
+
+The search's blocks merge their results with agent-scope atomics and hand them to the last arriver of a query block WITHOUT
+an agent-scope release fence (bf_hamming.hip, "Arrival ticket").  That is only sound while the compiler keeps emitting what
+the source asks for, so this test disassembles the code object inside ``libslamhip.so`` (llvm-objdump cross-disassembles; no
+GPU needed) and checks, in every kernel that contains the epilogue:
+
+  1. every ``global_atomic_umin`` is the RETURNING form (``sc0``): the merges into best[] and every write to bound[] - a
+     returned value is what tells the wave that the minimum has been taken at the memory side;
+  2. the arrival ticket is a returning ``global_atomic_add``; in front of it, in this order and with no vector-memory
+     instruction in between: ``s_waitcnt vmcnt(0)`` (every wave has its atomics back), ``s_barrier``;
+  3. the last arriver invalidates (``buffer_inv sc1``), waits (``s_waitcnt vmcnt(0)``), passes a barrier, and the first loads
+     behind it - the result slots - are ``sc1`` loads (never served from this CU's L1).
+
+A compiler upgrade that drops a return form or moves a wait fails here instead of racing silently.
+The epilogue of bf_top2_kernel<1, true, true> as built for round 4 is kept in profiles/r04_isa_handoff_excerpt.txt."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+VMEM = re.compile(r"^(global_|buffer_(?!inv|wbl2)|flat_|scratch_)")
+
+
+def disassemble(lib_path, workdir):
+    """{kernel name: [instruction, ...]} of every gfx950 code object bundled in the library."""
+    local = os.path.join(workdir, "lib.so")
+    shutil.copy(lib_path, local)
+    subprocess.run([OBJDUMP, "--offloading", local], cwd=workdir, check=True, capture_output=True)
+    funcs = {}
+    for name in sorted(os.listdir(workdir)):
+        if "gfx950" not in name:
+            continue
+        text = subprocess.run([OBJDUMP, "-d", os.path.join(workdir, name)], check=True, capture_output=True, text=True).stdout
+        cur = None
+        for line in text.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(.+)>:$", line)
+            if m:
+                label = m.group(1)
+                if not re.match(r"^L\w+_\d+$", label):            # the scan's local labels (Lgroup_3 ...) stay inside their kernel
+                    cur = funcs.setdefault(label, [])
+                continue
+            ins = line.split("//")[0].strip()
+            if cur is not None and ins and not ins.startswith("."):
+                cur.append(ins)
+    return funcs
+
+
+@pytest.fixture(scope="module")
+def kernels(built, tmp_path_factory):
+    if not os.path.exists(OBJDUMP):
+        pytest.skip("llvm-objdump of the ROCm toolchain not found")
+    from slamhip import _lib
+
+    funcs = disassemble(_lib.LIB_PATH, str(tmp_path_factory.mktemp("isa")))
+    found = {k: v for k, v in funcs.items() if "bf_top2" in k and "kernel" in k}
+    assert len(found) >= 6, sorted(funcs)[:20]          # R = 8, 4, 2; R = 1 through LDS / SGPRs / as a queue; the batch kernel
+    return found
+
+
+def test_every_merge_atomic_returns(kernels):
+    for name, ins in kernels.items():
+        umin = [i for i in ins if i.startswith("global_atomic_umin")]
+        assert len(umin) >= 3, (name, len(umin))
+        bad = [i for i in umin if " sc0" not in i]
+        assert not bad, f"{name}: atomic minimum without a return value: {bad[:3]}"
+        assert not [i for i in ins if i.startswith(("flat_atomic", "global_atomic_cmpswap"))], name
+
+
+def test_ticket_sits_behind_wait_and_barrier_and_the_last_arriver_reads_past_l1(kernels):
+    checked = 0
+    for name, ins in kernels.items():
+        inv = [k for k, i in enumerate(ins) if i.startswith("buffer_inv sc1")]
+        assert inv, f"{name}: no agent-scope invalidate - the last arriver's acquire is gone"
+        assert not [i for i in ins if i.startswith("buffer_wbl2")], f"{name}: a release fence is back: say so in bf_hamming.hip"
+        for at in inv:
+            # backwards: the ticket
+            k = at
+            while k >= 0 and not ins[k].startswith("global_atomic_add"):
+                assert not VMEM.match(ins[k]) , f"{name}: {ins[k]} between the ticket and the invalidate"
+                k -= 1
+            assert k >= 0 and " sc0" in ins[k], f"{name}: the arrival ticket must return its value"
+            ticket = k
+            # backwards from the ticket: barrier, then the wait, with no vector-memory instruction in between
+            k = ticket - 1
+            seen_barrier = False
+            while k >= 0:
+                i = ins[k]
+                if i.startswith("s_barrier"):
+                    seen_barrier = True
+                elif i.startswith("s_waitcnt") and "vmcnt(0)" in i and seen_barrier:
+                    break
+                else:
+                    assert not VMEM.match(i), f"{name}: {i} between the waves' wait and the ticket"
+                k -= 1
+            assert k >= 0 and seen_barrier, f"{name}: no s_waitcnt vmcnt(0) + s_barrier in front of the ticket"
+            # forwards from the invalidate: wait, barrier, sc1 loads
+            k = at + 1
+            waited = barrier = False
+            while k < len(ins) and not ins[k].startswith(("global_load", "buffer_load", "flat_load")):   # (block layout may put a store first)
+                waited = waited or (ins[k].startswith("s_waitcnt") and "vmcnt(0)" in ins[k])
+                barrier = barrier or (ins[k].startswith("s_barrier") and waited)
+                k += 1
+            assert waited and barrier, f"{name}: the invalidate is not waited for in front of the barrier"
+            assert k < len(ins) and ins[k].startswith("global_load_dwordx2") and ins[k].rstrip().endswith("sc1"), \
+                f"{name}: the result slots must be read by sc1 loads, found {ins[k] if k < len(ins) else None}"
+            checked += 1
+    assert checked >= 7                                  # the batch kernel carries the epilogue twice (both feeds)
+
+
+def test_queue_tickets_return(kernels):
+    """The queue kernel draws its chunk tickets with returning agent-scope adds as well (two sites + the arrival)."""
+    name = next(k for k in kernels if "ILi1ELb1ELb1E" in k)
+    adds = [i for i in kernels[name] if i.startswith("global_atomic_add")]
+    assert len(adds) >= 3 and all(" sc0" in i for i in adds), adds
