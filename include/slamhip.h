@@ -56,7 +56,9 @@ enum slam_status {
     SLAM_ERR_HIP = -2,       /* a HIP runtime call failed */
     SLAM_ERR_NO_DEVICE = -3, /* no gfx950 device visible */
     SLAM_ERR_RCCL = -4,      /* RCCL missing or a collective failed */
-    SLAM_ERR_STATE = -5      /* call made in the wrong state (e.g. comm not initialised) */
+    SLAM_ERR_STATE = -5,     /* call made in the wrong state (e.g. comm not initialised) */
+    SLAM_ERR_BUSY = -6       /* a resource condition, not a caller error: a kernel that needs all its workgroups resident at
+                                once (slam_ba_optimize_f64) could not get them - retry, or use the multi-launch form */
 };
 
 /* descriptor geometry: 256-bit ORB descriptors, one row = 32 bytes
@@ -343,19 +345,23 @@ SLAM_API int slam_ba_backsub_f64(slam_ctx* ctx, int64_t L, const int32_t* d_pt_p
  *             half `d_stats[6]` of both (the halves swap roles on every accepted step).
  *   index tables as slam_ba_reduce_f64 (obs_pose / obs_point [O], pt_ptr [L+1] / pt_obs [O], ps_ptr [K+1] / ps_obs [O]);
  *             a (pose, point) pair may be observed once; the (pose, point) -> observation table is built on the device.  A
- *             pose or point index outside the window is counted (slam_index_errors) and ends the launch (status 1); the
- *             four CSR arrays are trusted (slam_ba_optimize_host_f64 builds them itself).
+ *             pose or point index outside the window, a free list that is not ascending below K, or pose list heads that
+ *             are not 0 = ps_ptr[0] <= ... <= ps_ptr[K] = O are counted (slam_index_errors) and end the launch (status 2);
+ *             pt_ptr and the two observation lists are trusted (slam_ba_optimize_host_f64 builds all of them itself).
  *   d_free_poses int32 [n_free], ascending: the poses that move (the others hold the gauge).
  *   d_work    scratch of slam_ba_optimize_workspace(K, L, O) bytes, 16-byte aligned.
  *   d_stats   double [8]: initial cost, final cost, accepted steps, trials, final lambda, status (0 = ok; all NaN until the
- *             launch has completed, 1 if the launch was abandoned), result half, workgroups used.
+ *             launch has completed; 1 = abandoned at a grid barrier: device busy; 2 = bad index / table), result half,
+ *             workgroups used.
  * Schedule: lambda0 = 1e-5 max diag(H of the free poses and of the points); `iterations` iterations of up to 10 trials;
  * rho = (cost - cost_new) / (dx.(lambda dx - b) + 1e-3); accepted: lambda *= max(1/3, min(1 - (2 rho - 1)^3, 2/3));
  * rejected (or a factorisation that fails): lambda *= ni, ni *= 2.  Every sum is formed in a fixed order: two runs
  * give identical bits.  Asynchronous on the ctx stream.  The launch holds one compute unit per workgroup (at most 128, see
  * d_stats[7]) from start to end and needs all of them resident at once: launches of other contexts run beside it while
- * their workgroups fit as well (two of the largest do); one that cannot get its workgroups resident gives up after a
- * bounded wait and reports status 1. */
+ * their workgroups fit as well (two of the largest do).  A launch larger than the device could ever hold is refused
+ * (SLAM_ERR_BUSY); one that cannot get its workgroups resident NOW - other work holds compute units - gives up at a barrier
+ * after 50 ms of wall clock and reports status 1, which slam_ba_optimize_host_f64 returns as SLAM_ERR_BUSY: the window is
+ * unchanged and slam_ba_reduce_f64 / slam_ba_backsub_f64 (no residency requirement) do the same job. */
 #define SLAM_BA_LM_MAX_FREE 16
 #define SLAM_BA_LM_MAX_OBS (1 << 17)
 SLAM_API int slam_ba_optimize_workspace(int64_t K, int64_t L, int64_t O, uint64_t* bytes);
@@ -367,7 +373,8 @@ SLAM_API int slam_ba_optimize_f64(slam_ctx* ctx, int64_t K, int64_t L, int64_t O
                                   uint64_t work_bytes, double* d_stats);
 /* slam_ba_optimize_f64 on HOST buffers: poses [K,12] and points [L,3] in, the optimised ones out; the index tables the kernel
  * wants are built inside (two stable counting sorts), a (pose, point) pair observed twice or an index out of range is
- * refused (SLAM_ERR_INVALID) before anything is launched.  h_pose_fixed [K]: non-zero = the pose holds the gauge.  One
+ * refused (SLAM_ERR_INVALID) before anything is launched; SLAM_ERR_BUSY = the launch gave up at a grid barrier (see above),
+ * the outputs are not written.  h_pose_fixed [K]: non-zero = the pose holds the gauge.  One
  * upload, one launch, one download; staging, device arena and workspace belong to the context.  h_stats as d_stats above.
  * Serialises with the other host-buffer calls of the context. */
 SLAM_API int slam_ba_optimize_host_f64(slam_ctx* ctx, int64_t K, int64_t L, int64_t O, const double* h_poses,

@@ -145,13 +145,17 @@ class Backend:
         7 keyframes, ``backend.py:11``) is optimised in ONE kernel launch (``slam_ba_optimize_f64``: the whole LM loop,
         dense solve included, on the device); larger windows run the linearisation, the elimination of the landmarks,
         the blocks of the reduced camera system and the back-substitution on the GPU (``slam_ba_reduce_f64`` /
-        ``slam_ba_backsub_f64``) and solve the 6K x 6K system on the host.  With ``on_device=False`` only residuals
+        ``slam_ba_backsub_f64``) and solve the 6K x 6K system on the host - also what a one-launch attempt falls back to when it
+        reports a busy device (``slamhip.SlamHipBusy``).  With ``on_device=False`` only residuals
         and Jacobians come from the GPU and numpy does the rest.  Returns ``slamhip.ba.BAResult``."""
         fn = _ba.bundle_adjust
         if on_device:
             n_free = len(poses) - len(set(fixed_poses))
             one_launch = n_free <= _ba.ONE_LAUNCH_MAX_FREE and len(obs_pose_idx) <= _ba.ONE_LAUNCH_MAX_OBS and len(poses) <= 64
-            fn = _ba.bundle_adjust_one_launch if one_launch else _ba.bundle_adjust_device
+            # the one-launch form needs all its workgroups resident at once; when the device is busy with the tracking
+            # thread's work (slam.py:27-35) it gives up in bounded time (SlamHipBusy) and bundle_adjust_auto runs the
+            # per-phase kernels instead, once: the adjustment is slower then, it does not fail
+            fn = _ba.bundle_adjust_auto if one_launch else _ba.bundle_adjust_device
         return fn(poses, points, obs_pose_idx, obs_point_idx, meas, (fx, fy, cx, cy), iterations, fixed_poses,
                   huber_delta, ctx=self.ctx)
 

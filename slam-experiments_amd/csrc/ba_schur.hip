@@ -495,6 +495,18 @@ struct bg_args {
 template <typename T>
 __device__ __forceinline__ T bg_load(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// Why a launch ends early (bg_ctl::abort, d_stats[5]): 1 = a grid barrier was abandoned (the workgroups did not all become
+// resident in time: the device is busy with somebody else's work - a RESOURCE condition, SLAM_ERR_BUSY), 2 = an index
+// outside the window or a malformed index table (caller error, SLAM_ERR_INVALID).  The larger code wins.
+#define BG_ABORT_BUSY 1
+#define BG_ABORT_INDEX 2
+// A barrier gives up after BG_BARRIER_TICKS of the 100 MHz wall clock (50 ms; a whole window adjustment at the reference's
+// size takes 0.3 ms) - bounded by TIME, not by a poll count whose duration depends on what else the memory system is doing
+// (the 2^22 polls of round 3 measured 0.56-0.67 s on an idle chip, 133-160 ns each, and more under load:
+// profiles/r04_ba_busy.log) - with a poll cap behind it.
+#define BG_BARRIER_TICKS 5000000ull
+__device__ __forceinline__ void bg_abort(bg_ctl* c, int why) { atomicMax(&c->abort, why); }
+
 // returns false when the launch is being abandoned
 __device__ __forceinline__ bool bg_grid_sync(bg_ctl* c, unsigned int nblocks, unsigned int& gen) {
     __syncthreads();                                         // every wave's stores are issued and drained
@@ -506,10 +518,15 @@ __device__ __forceinline__ bool bg_grid_sync(bg_ctl* c, unsigned int nblocks, un
             __hip_atomic_fetch_add(&c->gen, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         } else {
             unsigned int polls = 0;
+            const unsigned long long t0 = wall_clock64();
             while (__hip_atomic_load(&c->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
-                if (++polls > (1u << 22) || ((polls & 63) == 0 && __hip_atomic_load(&c->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-                    __hip_atomic_store(&c->abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
+                ++polls;
+                if ((polls & 63) == 0) {
+                    if (__hip_atomic_load(&c->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                    if (wall_clock64() - t0 > BG_BARRIER_TICKS || polls > (1u << 26)) {
+                        bg_abort(c, BG_ABORT_BUSY);
+                        break;
+                    }
                 }
                 __builtin_amdgcn_s_sleep(2);
             }
@@ -922,9 +939,24 @@ __global__ __launch_bounds__(BA_THREADS) void ba_lm_grid_kernel(const bg_args a)
         const int k = a.obs_pose[o], l = a.obs_point[o];
         if ((unsigned)k >= (unsigned)K || (unsigned)l >= (unsigned)L) {
             atomicAdd(a.index_errors, 1u);
-            __hip_atomic_store(&c->abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bg_abort(c, BG_ABORT_INDEX);
         } else {
             a.lookup[(size_t)k * L + l] = o;
+        }
+    }
+    // the small tables that index LDS arrays and the per-pose blocks: the free list (ascending, below K) and the poses' list
+    // heads (0 = ps_ptr[0] <= ... <= ps_ptr[K] = O); a device-array caller's mistake there would be an out-of-bounds access
+    // (ADVICE r03).  The per-point heads pt_ptr / the two observation lists stay trusted: O + L entries, and
+    // slam_ba_optimize_host_f64 builds them itself.
+    if (blk == 0) {
+        for (int i = tid; i < nf; i += BA_THREADS) {
+            const int f = a.free_list[i];
+            if ((unsigned)f >= (unsigned)K || (i > 0 && a.free_list[i - 1] >= f)) { atomicAdd(a.index_errors, 1u); bg_abort(c, BG_ABORT_INDEX); }
+        }
+        for (int i = tid; i <= K; i += BA_THREADS) {
+            const int v = a.ps_ptr[i];
+            const bool bad = v < 0 || v > O || (i == 0 && v != 0) || (i == K && v != O) || (i > 0 && a.ps_ptr[i - 1] > v);
+            if (bad) { atomicAdd(a.index_errors, 1u); bg_abort(c, BG_ABORT_INDEX); }
         }
     }
     BG_SYNC_OR_QUIT();
@@ -1273,6 +1305,17 @@ extern "C" int slam_ba_optimize_f64(slam_ctx* ctx, int64_t K, int64_t L, int64_t
     a.index_errors = slam_index_error_counter(ctx);
     a.cam = {fx, fy, cx, cy};
     a.delta = huber_delta;
+    // Every workgroup has to be resident at once (hand-made grid barriers): refuse what this device could never hold; what
+    // it cannot hold RIGHT NOW (other work on the compute units) is found out by the barriers themselves, in bounded time.
+    static int blocks_per_cu = 0;                  // a property of the kernel and the architecture: computed once
+    if (!blocks_per_cu) {
+        int occ = 0;
+        SLAM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, ba_lm_grid_kernel, BA_THREADS, 0));
+        blocks_per_cu = occ > 0 ? occ : -1;
+    }
+    if (blocks_per_cu < 0 || (int64_t)blocks_per_cu * ctx->num_cu < a.nblocks)
+        return slam_set_error(SLAM_ERR_BUSY, "slam_ba_optimize_f64: %d workgroups cannot be resident at once on %d compute units",
+                              a.nblocks, ctx->num_cu);
     // the control block starts as: barrier idle, no abort, state in half 0
     SLAM_HIP(hipMemsetAsync(a.ctl, 0, sizeof(bg_ctl), ctx->stream));                           // (workgroup 0 fills in the rest before the first barrier)
     SLAM_HIP(hipMemsetAsync(d_stats, 0xFF, 64, ctx->stream));                                  // all-NaN until the launch completes

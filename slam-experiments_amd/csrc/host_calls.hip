@@ -313,8 +313,14 @@ extern "C" int slam_ba_optimize_host_f64(slam_ctx* ctx, int64_t K, int64_t L, in
     SLAM_HIP(hipMemcpyAsync(hb + off_T, db + off_T, total - off_T, hipMemcpyDeviceToHost, ctx->stream));
     SLAM_HIP(hipStreamSynchronize(ctx->stream));
     memcpy(h_stats, hb + off_st, 64);
-    const bool fine = h_stats[5] == 0.0 && h_stats[6] == h_stats[6];
-    SLAM_REQUIRE(fine, "slam_ba_optimize_f64 did not complete (its grid barrier was abandoned)");
+    if (h_stats[5] == 2.0)      // the device-side table checks (the host checks above make this unreachable from here)
+        return slam_set_error(SLAM_ERR_INVALID, "slam_ba_optimize_f64: an index outside the window or a malformed index table");
+    if (!(h_stats[5] == 0.0 && h_stats[6] == h_stats[6]))
+        // not the caller's fault: the launch could not get all its workgroups resident within the barriers' time limit (other
+        // work holds compute units).  The window is untouched on the host; slam_ba_reduce_f64 / slam_ba_backsub_f64 (no
+        // residency requirement) do the same adjustment.
+        return slam_set_error(SLAM_ERR_BUSY, "slam_ba_optimize_f64 gave up at a grid barrier (device busy): status %g after %g trials",
+                              h_stats[5], h_stats[3]);
     const int half = h_stats[6] != 0.0 ? 1 : 0;
     memcpy(h_poses_out, hb + off_T + (uint64_t)half * K * 96, (size_t)K * 96);
     memcpy(h_points_out, hb + off_X + (uint64_t)half * L * 24, (size_t)L * 24);

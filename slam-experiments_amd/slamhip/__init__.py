@@ -1,6 +1,6 @@
 """slamhip — MI355X (gfx950) kernels for the descriptor-matching / reprojection
 hot path of ViV99/slam-experiments, behind a ctypes C ABI (include/slamhip.h)."""
-from ._lib import NO_MATCH_DIST, NO_MATCH_IDX, SlamHipError, device_count, load  # noqa: F401
+from ._lib import NO_MATCH_DIST, NO_MATCH_IDX, SlamHipBusy, SlamHipError, device_count, load  # noqa: F401
 from .device import Context, DeviceBuffer, default_context, plan_describe  # noqa: F401
 from .matching import (  # noqa: F401
     NORM_HAMMING,

@@ -28,6 +28,15 @@ class SlamHipError(RuntimeError):
         self.code = code
 
 
+class SlamHipBusy(SlamHipError):
+    """SLAM_ERR_BUSY (-6): a resource condition, not a caller error - a kernel that needs all its workgroups resident at once
+    could not get them (other work holds compute units).  Inputs and outputs are untouched; retry, or use the form without
+    a residency requirement."""
+
+
+SLAM_ERR_INVALID, SLAM_ERR_BUSY = -1, -6
+
+
 # name -> (restype, argtypes); must list every SLAM_API symbol of include/slamhip.h
 SIGNATURES = {
     "slam_last_error": (c_char_p, []),
@@ -141,7 +150,7 @@ def load() -> ctypes.CDLL:
 def check(rc: int) -> None:
     if rc != SLAM_OK:
         msg = load().slam_last_error()
-        raise SlamHipError(rc, msg.decode("utf-8", "replace") if msg else "unknown error")
+        raise (SlamHipBusy if rc == SLAM_ERR_BUSY else SlamHipError)(rc, msg.decode("utf-8", "replace") if msg else "unknown error")
 
 
 def device_count() -> int:

@@ -15,7 +15,7 @@ from typing import Optional, Sequence
 
 import numpy as np
 
-from ._lib import SlamHipError, check
+from ._lib import SLAM_ERR_INVALID, SlamHipBusy, SlamHipError, check
 from .device import Context, default_context
 from .pose_opt import se3_exp
 from .reproj import ReprojProblem, poses_to_rt12
@@ -255,7 +255,12 @@ def bundle_adjust_one_launch(poses, points, obs_pose_idx, obs_point_idx, meas, i
     """``bundle_adjust_device`` with the whole Levenberg-Marquardt loop in ONE kernel launch (``slam_ba_optimize_f64``):
     the window goes up once, the dense reduced system is solved on the device, the trials, their costs and the accept /
     reject decisions never leave it, the result comes back once.  For windows of at most 16 moving poses (the reference
-    keeps 7 keyframes, ``backend.py:11``)."""
+    keeps 7 keyframes, ``backend.py:11``).
+
+    Raises ``ValueError`` for bad arguments and ``SlamHipBusy`` when the launch gave up at one of its grid barriers because
+    other work held compute units (it needs all its workgroups resident at once): nothing was changed, and
+    ``bundle_adjust_device`` - per-phase kernels, no residency requirement - does the same adjustment (``bundle_adjust_auto``
+    and ``Backend.optimize`` fall back to it by themselves)."""
     ctx = ctx or default_context()
     P = np.asarray(poses, np.float64)
     T12 = np.ascontiguousarray((P.reshape(-1, 12) if P.ndim == 2 else poses_to_rt12(P)).reshape(-1, 12))
@@ -279,12 +284,28 @@ def bundle_adjust_one_launch(poses, points, obs_pose_idx, obs_point_idx, meas, i
                                                 meas.ctypes.data, fixed.ctypes.data, fx, fy, cx, cy, float(huber_delta), int(iterations),
                                                 Tout.ctypes.data, Xout.ctypes.data, st.ctypes.data))
     except SlamHipError as exc:
-        if exc.code == -1:                       # SLAM_ERR_INVALID: a bad argument, e.g. an index out of range or a pair observed twice
+        if exc.code == SLAM_ERR_INVALID:         # a bad argument, e.g. an index out of range or a pair observed twice
             raise ValueError(str(exc)) from None
-        raise
+        raise                                    # SlamHipBusy (device busy: not the caller's fault) and HIP errors as they are
     Tr = np.tile(np.eye(4), (K, 1, 1))
     Tr[:, :3, :4] = Tout.reshape(K, 3, 4)
     return BAResult(poses=Tr, points=Xout, chi2_initial=float(st[0]), chi2_final=float(st[1]), iterations=int(st[2]))
+
+
+def bundle_adjust_auto(poses, points, obs_pose_idx, obs_point_idx, meas, intrinsics, iterations: int = 10,
+                       fixed_poses: Sequence[int] = (0,), huber_delta: float = 0.0, ctx: Optional[Context] = None,
+                       on_busy=None) -> BAResult:
+    """``bundle_adjust_one_launch``, and when that reports a busy device (``SlamHipBusy``) the same adjustment ONCE more
+    through ``bundle_adjust_device``, whose kernels need no co-residency: a GPU that is shared with the tracking thread's
+    searches (``slam.py:27-35``: tracking and backend are two threads) slows the window adjustment down, it does not fail it.
+    ``on_busy(exc)`` is called when the fall-back is taken."""
+    args = (poses, points, obs_pose_idx, obs_point_idx, meas, intrinsics, iterations, fixed_poses, huber_delta)
+    try:
+        return bundle_adjust_one_launch(*args, ctx=ctx)
+    except SlamHipBusy as exc:
+        if on_busy is not None:
+            on_busy(exc)
+        return bundle_adjust_device(*args, ctx=ctx)
 
 
 def bundle_adjust_device(poses, points, obs_pose_idx, obs_point_idx, meas, intrinsics, iterations: int = 10,

@@ -331,3 +331,48 @@ def test_map_discovery_skips_decoys_and_names_what_it_found(tmp_path):
         sys.path[:] = saved
         backend.__dict__.pop("Map", None)
         importlib.invalidate_caches()
+
+
+def test_busy_one_launch_ba_falls_back_to_the_per_phase_kernels(monkeypatch):
+    """SLAM_ERR_BUSY (-6) is a resource condition: `check` raises SlamHipBusy (a SlamHipError, not a ValueError),
+    bundle_adjust_one_launch lets it through, and bundle_adjust_auto / Backend.optimize run the same window ONCE more through
+    bundle_adjust_device; SLAM_ERR_INVALID (-1) stays a ValueError and is not retried.  No GPU: the library is a stand-in
+    that returns the status codes."""
+    import backend
+    import slamhip
+    from slamhip import _lib as L
+    from slamhip import ba
+
+    class Lib:
+        def __init__(self, rc): self.rc, self.calls = rc, 0
+        def slam_ba_optimize_host_f64(self, *a): self.calls += 1; return self.rc
+        def slam_last_error(self): return b"slam_ba_optimize_f64 gave up at a grid barrier (device busy)"
+
+    class Ctx:
+        def __init__(self, rc): self.lib, self.handle = Lib(rc), None
+
+    assert issubclass(slamhip.SlamHipBusy, slamhip.SlamHipError) and not issubclass(slamhip.SlamHipBusy, ValueError)
+    args = (np.tile(np.eye(4), (3, 1, 1)), np.ones((4, 3)), [0, 1, 2], [0, 1, 2], np.zeros((3, 2)), (1.0, 1.0, 0.0, 0.0))
+    fell_back = []
+    monkeypatch.setattr(ba, "bundle_adjust_device", lambda *a, **k: fell_back.append(k.get("ctx")) or "per-phase result")
+    old = L._lib
+    try:
+        busy = Ctx(-6)
+        L._lib = busy.lib
+        with pytest.raises(slamhip.SlamHipBusy) as err:
+            ba.bundle_adjust_one_launch(*args, ctx=busy)
+        assert err.value.code == -6 and "busy" in str(err.value)
+        seen = []
+        assert ba.bundle_adjust_auto(*args, ctx=busy, on_busy=seen.append) == "per-phase result"
+        assert busy.lib.calls == 2 and fell_back == [busy] and isinstance(seen[0], slamhip.SlamHipBusy)
+        bk = backend.Backend()
+        bk._ctx = busy
+        assert bk.optimize(args[0], args[1], args[2], args[3], args[4], 1.0, 1.0, 0.0, 0.0) == "per-phase result"
+        assert busy.lib.calls == 3 and len(fell_back) == 2
+        invalid = Ctx(-1)
+        L._lib = invalid.lib
+        with pytest.raises(ValueError):
+            ba.bundle_adjust_auto(*args, ctx=invalid)
+        assert invalid.lib.calls == 1 and len(fell_back) == 2            # a caller error is not retried
+    finally:
+        L._lib = old
