@@ -189,6 +189,17 @@ SLAM_API int slam_bf_reset_state(slam_ctx* ctx);
  * so the tests and tools/stress_state.py assert on this directly. */
 SLAM_API int slam_bf_state_dirty(slam_ctx* ctx, int64_t* h_words);
 
+/* slam_bf_knn2_u256 and a selection in ONE launch, for the selections that need no reduction over the queries: the block
+ * that decodes a query block's result flags its queries as it writes them.
+ *   mode 0: 1-NN of every query that has one (bf.match, feature_matchers.py:39,44)
+ *   mode 2: Lowe ratio, kept iff dist0 < param * dist1 (strict; needs 2 neighbours) - BASELINE configs[1]
+ * d_keep uint8 [N] (1 = kept); *h_count = rows kept, after one synchronisation (h_count NULL: asynchronous, no count).  Same
+ * flags and count as slam_bf_knn2_u256 + slam_bf_match_filter; mode 1 (the min-distance filter) needs the global minimum
+ * and stays there.  Train sets of more than 2^23 rows and empty ones run the two steps internally. */
+SLAM_API int slam_bf_knn2_select_u256(slam_ctx* ctx, const void* d_query, int64_t N, const void* d_train, int64_t M,
+                                      int64_t train_base, int32_t* d_idx, int32_t* d_dist, int mode, double param,
+                                      uint8_t* d_keep, int64_t* h_count);
+
 /* Post-match selection on the device (feature_matchers.py:41-43 and the
  * OpenCV knn / ratio semantics).  Input: the [N,2] tables above.
  *   mode 0: 1-NN of every query that has one                 (bf.match, feature_matchers.py:39,44)

@@ -301,6 +301,18 @@ struct bf_state {
                                 // 256-row chunk cost 168 us where one block per chunk took 157: profiles/r04_ab_queue.log)
 };
 
+// Selection fused into the decode (round 4): the last arriver of a query block has (k1, k2) of its queries
+// in hand, so the selections that need NO reduction over the queries - "has a neighbour" (bf.match, feature_matchers.py:39,44)
+// and the Lowe ratio test - are made there: one flag per query, and how many each wave kept (a plain store per wave: nothing
+// to zero beforehand, the host adds them up).  A search + ratio test on resident rows is ONE launch instead of two.
+struct bf_select {
+    uint8_t* keep;        // [N] 1 = kept; null = no selection
+    int* wave_kept;       // [ceil(N / 64)] rows kept in each group of 64 consecutive queries (device or pinned host memory)
+    double param;         // mode 2: the ratio
+    int mode;             // 0 = keep every query that has a neighbour, 2 = Lowe ratio: dist0 < param * dist1 (needs two neighbours)
+    int pad;
+};
+
 // grid.x = query blocks of 256*R rows, grid.y = train chunks: block (x, y) scans rows [tbl[y], tbl[y+1]).  Every block
 // merges its top-2 into st.best; the last block to arrive for a query block decodes (idx + train_base, dist) and
 // restores the merge state.  Blocks with y < lead are the leaders: short chunks at the head of the dispatch order that,
@@ -315,7 +327,8 @@ __device__ __forceinline__ void bf_top2_block(const uint4* __restrict__ q, int N
                                               const int* __restrict__ tbl, int lead, bf_state st, int train_base,
                                               int2* __restrict__ out_idx, int2* __restrict__ out_dist,
                                               uint4* __restrict__ keep, const int bx, const int by, const int S,
-                                              const int cold_arg, const int uni_arg, const int M, const int nchunks, const int merge_arg) {
+                                              const int cold_arg, const int uni_arg, const int M, const int nchunks, const int merge_arg,
+                                              const bf_select sel) {
     // QUEUE is a template parameter, not a run-time flag: with both forms in one kernel the one-block-per-chunk plans ran
     // 1-2.5 % slower than without the queue code (30 SGPR spills instead of 3; profiles/r04_ab_queue.log).  A queue plan has
     // a boundary table, exchanges bounds and has no leaders.
@@ -698,6 +711,7 @@ __device__ __forceinline__ void bf_top2_block(const uint4* __restrict__ q, int N
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const int qi = qbase + r * 64;
+        int kept = 0;
         if (qi < N) {
             // every contribution was made by an agent-scope atomic; read it back the same way (never from L1)
             const unsigned long long v = __hip_atomic_load(&st.best[qi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -709,9 +723,20 @@ __device__ __forceinline__ void bf_top2_block(const uint4* __restrict__ q, int N
             od.y = k2 == SLAM_KEY_NONE ? SLAM_NO_MATCH_DIST : (int)(k2 >> SLAM_KEY_IDX_BITS);
             out_idx[qi] = oi;
             out_dist[qi] = od;
+            if (sel.keep) {
+                // (double) comparisons of integers <= 256: exact, and the same arithmetic as filter_keep_kernel
+                const bool k = oi.x >= 0 && (sel.mode == 0 || (oi.y >= 0 && (double)od.x < sel.param * (double)od.y));
+                sel.keep[qi] = k ? 1 : 0;
+                kept = k ? 1 : 0;
+            }
             // restore the between-launch invariant for these queries (all other blocks are done with them)
             __hip_atomic_store(&st.best[qi], ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (!merging) __hip_atomic_store(&st.bound[qi], SLAM_BOUND_IDLE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (sel.keep && qi - lane < N) {                   // (wave-uniform: the group's first query exists)
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) kept += __shfl_xor(kept, off, 64);
+            if (lane == 0) sel.wave_kept[qi >> 6] = kept;
         }
     }
     if (tid == 0) __hip_atomic_store(&st.arrivals[bx], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -725,7 +750,7 @@ __global__ __launch_bounds__(256) void bf_top2_kernel(const uint4* __restrict__ 
                                                       int lead, bf_state st, int train_base,
                                                       int2* __restrict__ out_idx, int2* __restrict__ out_dist,
                                                       uint4* __restrict__ keep, int cold, int uni, int M,
-                                                      int nchunks, int merge) {
+                                                      int nchunks, int merge, bf_select sel) {
     // Queue plans rotate the query blocks from one row of workers to the next: worker y of query block x is block
     // ((x - y) mod grid.x, y).  Blocks go to the XCDs round robin by their linear index, so without the rotation ALL workers
     // of a query block sit on one XCD (grid.x is a multiple of 8 for the big grids) - and the XCDs do not run at the same
@@ -737,7 +762,7 @@ __global__ __launch_bounds__(256) void bf_top2_kernel(const uint4* __restrict__ 
     int bx = (int)blockIdx.x;
     if (QUEUE) bx = (bx + (int)blockIdx.y) % (int)gridDim.x;
     bf_top2_block<R, SFEED, QUEUE>(q, N, t, tbl, lead, st, train_base, out_idx, out_dist, keep, bx, (int)blockIdx.y,
-                            (int)gridDim.y, cold, uni, M, nchunks, merge);
+                            (int)gridDim.y, cold, uni, M, nchunks, merge, sel);
 }
 
 // ---- several independent searches in ONE launch -------------------------------------------------------------------
@@ -765,10 +790,10 @@ __global__ __launch_bounds__(256) void bf_top2_batch_kernel(const bf_batch b) {
     const int bx = local % p.qblocks, by = local / p.qblocks;
     if (p.sfeed)   // block-uniform: the search's train rows travel through SGPRs (short or long chunks in device memory)
         bf_top2_block<1, true, false>(p.q, p.N, p.t, p.tbl, p.lead, p.st, p.train_base, p.out_idx, p.out_dist, p.keep, bx, by, p.S, p.cold,
-                               p.uni, p.M, 0, 0);
+                               p.uni, p.M, 0, 0, bf_select{});
     else
         bf_top2_block<1, false, false>(p.q, p.N, p.t, p.tbl, p.lead, p.st, p.train_base, p.out_idx, p.out_dist, p.keep, bx, by, p.S, p.cold,
-                                p.uni, p.M, 0, 0);
+                                p.uni, p.M, 0, 0, bf_select{});
 }
 
 // merge G decoded tables by (dist, idx)
@@ -1253,7 +1278,7 @@ extern "C" int slam_bf_state_dirty(slam_ctx* ctx, int64_t* h_words) {
 
 // one pass over at most 2^23 train rows
 static int bf_pass(slam_ctx* ctx, const void* d_query, int64_t N, const void* d_train, int64_t M,
-                   int64_t train_base, int32_t* d_idx, int32_t* d_dist, void* d_keep) {
+                   int64_t train_base, int32_t* d_idx, int32_t* d_dist, void* d_keep, const bf_select sel = bf_select{}) {
     std::vector<int> tbl;
     const bf_plan p = make_plan(ctx, N, M, &tbl, 0, bf_rows_on_host(ctx, d_train));
     bf_state st;
@@ -1280,7 +1305,7 @@ static int bf_pass(slam_ctx* ctx, const void* d_query, int64_t N, const void* d_
     SLAM_HIP(hipGetLastError());
     if (int rc = slam_prof_begin(ctx)) return rc;
 #define SLAM_BF_LAUNCH(R_, F_, Q_) \
-    bf_top2_kernel<R_, F_, Q_><<<grid, block, 0, ctx->stream>>>(q, (int)N, t, d_tbl, p.lead, st, tb, oi, od, (uint4*)d_keep, p.cold, p.uni, (int)M, nchunks, p.merge)
+    bf_top2_kernel<R_, F_, Q_><<<grid, block, 0, ctx->stream>>>(q, (int)N, t, d_tbl, p.lead, st, tb, oi, od, (uint4*)d_keep, p.cold, p.uni, (int)M, nchunks, p.merge, sel)
     switch (p.R) {
         case 8: SLAM_BF_LAUNCH(8, false, false); break;
         case 4: SLAM_BF_LAUNCH(4, false, false); break;
@@ -1342,6 +1367,63 @@ int slam_bf_knn2_keep(slam_ctx* ctx, const void* d_query, int64_t N, const void*
             return rc;
     }
     return slam_bf_merge_top2(ctx, idx_parts, dist_parts, passes, N, d_idx, d_dist);
+}
+
+// slam_bf_knn2_u256 + a selection that needs no reduction over the queries, in ONE launch (see bf_select).  d_sel_keep u8 [N];
+// the rows kept by each wave land in pinned host memory owned by the context (written by the kernel itself: no copy command),
+// and *h_count is their sum after ONE synchronisation.  h_count may be null: then nothing is waited for (asynchronous, the
+// flags are in d_sel_keep when the stream gets there).  Train sets that need several passes and empty ones take the two-step
+// way (search, then slam_filter_launch).
+int slam_bf_knn2_select(slam_ctx* ctx, const void* d_query, int64_t N, const void* d_train, int64_t M, int64_t train_base,
+                        int32_t* d_idx, int32_t* d_dist, void* d_query_keep, int mode, double param, uint8_t* d_sel_keep,
+                        int64_t* h_count) {
+    SLAM_REQUIRE(ctx, "slam_bf_knn2_select_u256: null ctx");
+    SLAM_REQUIRE(mode == 0 || mode == 2, "slam_bf_knn2_select_u256: mode %d (0 = has a neighbour, 2 = Lowe ratio; the min-distance filter "
+                 "needs a reduction over the queries: slam_bf_match_filter)", mode);
+    SLAM_REQUIRE(N >= 0 && N <= (1ll << 30), "bad N=%lld", (long long)N);
+    if (h_count) *h_count = 0;
+    if (N == 0) return SLAM_OK;
+    SLAM_REQUIRE(d_sel_keep, "slam_bf_knn2_select_u256: null d_keep");
+    const bool fused = M > 0 && M <= SLAM_MAX_TRAIN_PER_PASS;
+    if (!fused) {
+        if (int rc = slam_bf_knn2_keep(ctx, d_query, N, d_train, M, train_base, d_idx, d_dist, d_query_keep)) return rc;
+        if (!h_count) return slam_filter_launch(ctx, d_idx, d_dist, N, mode, param, d_sel_keep);
+        return slam_bf_match_filter(ctx, d_idx, d_dist, N, mode, param, d_sel_keep, h_count, nullptr);
+    }
+    SLAM_REQUIRE(M >= 0 && d_query && d_train && d_idx && d_dist, "slam_bf_knn2_select_u256: null device pointer");
+    SLAM_REQUIRE(((uintptr_t)d_query & 15) == 0 && ((uintptr_t)d_train & 15) == 0 && ((uintptr_t)d_query_keep & 15) == 0,
+                 "descriptor pointers must be 16-byte aligned");
+    SLAM_REQUIRE(train_base >= 0 && train_base + M <= 0x7FFFFFFFll, "train_base + M must fit int32");
+    SLAM_HIP(hipSetDevice(ctx->device));
+    const int64_t waves = (N + 63) / 64;                            // groups of 64 consecutive queries
+    {
+        std::lock_guard<std::mutex> g(ctx->mu);
+        if ((uint64_t)waves * 4 > ctx->sel_host_bytes) {
+            SLAM_HIP(hipStreamSynchronize(ctx->stream));          // a queued search may still write the old block
+            if (ctx->sel_host) SLAM_HIP(hipHostFree(ctx->sel_host));
+            ctx->sel_host = nullptr;
+            ctx->sel_host_bytes = 0;
+            const uint64_t bytes = ((uint64_t)waves * 4 + 4095) / 4096 * 4096 * 2;
+            SLAM_HIP(hipHostMalloc(&ctx->sel_host, bytes, hipHostMallocDefault));
+            ctx->sel_host_bytes = bytes;
+        }
+    }
+    bf_select sel;
+    sel.keep = d_sel_keep; sel.wave_kept = (int*)ctx->sel_host; sel.param = param; sel.mode = mode; sel.pad = 0;
+    if (int rc = bf_pass(ctx, d_query, N, d_train, M, train_base, d_idx, d_dist, d_query_keep, sel)) return rc;
+    if (!h_count) return SLAM_OK;
+    SLAM_HIP(hipStreamSynchronize(ctx->stream));
+    int64_t c = 0;
+    const volatile int* wk = (const volatile int*)ctx->sel_host;
+    for (int64_t w = 0; w < waves; w++) c += wk[w];
+    *h_count = c;
+    return SLAM_OK;
+}
+
+extern "C" int slam_bf_knn2_select_u256(slam_ctx* ctx, const void* d_query, int64_t N, const void* d_train, int64_t M,
+                                        int64_t train_base, int32_t* d_idx, int32_t* d_dist, int mode, double param,
+                                        uint8_t* d_keep, int64_t* h_count) {
+    return slam_bf_knn2_select(ctx, d_query, N, d_train, M, train_base, d_idx, d_dist, nullptr, mode, param, d_keep, h_count);
 }
 
 // B independent searches in one launch (see bf_top2_batch_kernel).  h_keep: per search, where to leave a device copy of

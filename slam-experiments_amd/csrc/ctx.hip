@@ -75,6 +75,7 @@ extern "C" int slam_ctx_destroy(slam_ctx* ctx) {
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->io_dev) (void)hipFree(ctx->io_dev);
     if (ctx->io_host) (void)hipHostFree(ctx->io_host);
+    if (ctx->sel_host) (void)hipHostFree(ctx->sel_host);
     if (ctx->bf_state_mem) (void)hipFree(ctx->bf_state_mem);
     if (ctx->bf_tbl_ready) {
         (void)hipFree(ctx->bf_tbl_dev);

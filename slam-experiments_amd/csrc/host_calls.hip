@@ -162,12 +162,18 @@ extern "C" int slam_bf_match_host(slam_ctx* ctx, const uint8_t* h_query, int64_t
     }
     int32_t* d_idx = (int32_t*)(io + off_i);
     int32_t* d_dist = (int32_t*)(io + off_d);
-    if (int rc = slam_bf_knn2_keep(ctx, dq, N, dt, M, 0, d_idx, d_dist, keep_in_kernel)) return rc;
     // mode 0 (the reference's own call, dist_threshold=None, frontend.py:187) keeps every query that has a neighbour:
-    // that needs no reduction over the queries, so no selection kernel is launched for it (one launch less per frame)
+    // that needs no reduction over the queries, so no selection kernel is launched for it (one launch less per frame);
+    // the Lowe ratio test (mode 2) needs none either and is made by the search's own decode (slam_bf_knn2_select);
+    // the min-distance filter (mode 1, feature_matchers.py:41-43) needs the global minimum: its own kernel
     const bool select = mode != 0;
-    if (select)
-        if (int rc = slam_filter_launch(ctx, d_idx, d_dist, N, mode, param, io + off_k)) return rc;
+    if (mode == 2) {
+        if (int rc = slam_bf_knn2_select(ctx, dq, N, dt, M, 0, d_idx, d_dist, keep_in_kernel, 2, param, io + off_k, nullptr)) return rc;
+    } else {
+        if (int rc = slam_bf_knn2_keep(ctx, dq, N, dt, M, 0, d_idx, d_dist, keep_in_kernel)) return rc;
+        if (select)
+            if (int rc = slam_filter_launch(ctx, d_idx, d_dist, N, mode, param, io + off_k)) return rc;
+    }
     if (!zc) SLAM_HIP(hipMemcpyAsync(hb + off_i, db + off_i, (uint64_t)N * (select ? 17 : 16), hipMemcpyDeviceToHost, ctx->stream));
     SLAM_HIP(hipStreamSynchronize(ctx->stream));
     // compact the kept rows (for modes 1 and 2 the selection itself was made on the device)

@@ -32,6 +32,8 @@ struct slam_ctx {
     hipEvent_t bf_tbl_ev[SLAM_BF_TBL_RING] = {};
     int bf_tbl_cur = 0;                             // slot of the most recent search
     void* scratch = nullptr;                        // 4 KiB device scratch (filter counters, reductions)
+    void* sel_host = nullptr;                       // pinned host block the search's fused selection writes its per-wave counts to
+    uint64_t sel_host_bytes = 0;
     void* io_dev = nullptr;                         // device arena of the host-buffer entry points (grow-only)
     uint64_t io_dev_bytes = 0;
     void* io_host = nullptr;                        // pinned host staging for the same (grow-only)
@@ -75,6 +77,10 @@ int slam_io_arena(slam_ctx* ctx, uint64_t dev_bytes, uint64_t host_bytes, void**
 // for the copy to happen: with no train rows no kernel reads the queries)
 int slam_bf_knn2_keep(slam_ctx* ctx, const void* d_query, int64_t N, const void* d_train, int64_t M, int64_t train_base,
                       int32_t* d_idx, int32_t* d_dist, void* d_keep);
+// slam_bf_knn2_select_u256 with an optional copy of the query rows (d_query_keep) and an optional count (h_count null: no wait)
+int slam_bf_knn2_select(slam_ctx* ctx, const void* d_query, int64_t N, const void* d_train, int64_t M, int64_t train_base,
+                        int32_t* d_idx, int32_t* d_dist, void* d_query_keep, int mode, double param, uint8_t* d_sel_keep,
+                        int64_t* h_count);
 // slam_bf_knn2_batch_u256 with optional per-search copies of the query rows (h_keep[i] or null; h_keep may be null)
 int slam_bf_knn2_batch_keep(slam_ctx* ctx, int64_t B, const slam_bf_search* h_searches, void* const* h_keep);
 // the filter kernels of slam_bf_match_filter without the read-back (asynchronous on the ctx stream)

@@ -12,6 +12,7 @@ from .matching import (  # noqa: F401
     cross_check_arrays,
     knn2_device,
     knn2_device_batch,
+    knn2_select_device,
     knn_match_arrays,
     knn_match_arrays_batch,
     knn_match_collection,

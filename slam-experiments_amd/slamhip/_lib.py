@@ -58,6 +58,8 @@ SIGNATURES = {
     "slam_prof_read": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_double)]),
     "slam_bf_knn2_u256": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
     "slam_bf_knn2_batch_u256": (c_int, [c_void_p, c_int64, c_void_p]),
+    "slam_bf_knn2_select_u256": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int, c_double,
+                                         c_void_p, POINTER(c_int64)]),
     "slam_bf_merge_top2": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
     "slam_bf_knn2_u256_host": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p]),
     "slam_bf_set_tuning": (c_int, [c_void_p, POINTER(c_int32), c_int]),

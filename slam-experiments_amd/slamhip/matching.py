@@ -202,6 +202,19 @@ def match_arrays(source, query, dist_threshold: Optional[float] = None, ctx: Opt
     return out
 
 
+def knn2_select_device(ctx: Context, d_query: DeviceBuffer, n: int, d_train: DeviceBuffer, m: int, d_idx: DeviceBuffer,
+                       d_dist: DeviceBuffer, d_keep: DeviceBuffer, mode: int = MODE_RATIO, param: float = 0.75,
+                       train_base: int = 0) -> int:
+    """Top-2 search + selection in ONE launch on device-resident rows (``slam_bf_knn2_select_u256``): ``mode`` 0 keeps every
+    query that has a neighbour, 2 is the Lowe ratio test ``dist0 < param * dist1`` (BASELINE configs[1]: knn = 2 + ratio).
+    The tables go to ``d_idx`` / ``d_dist`` as ``knn2_device`` leaves them, one flag per query to ``d_keep`` (uint8 [n]);
+    returns how many were kept (one synchronisation)."""
+    cnt = ctypes.c_int64(0)
+    check(ctx.lib.slam_bf_knn2_select_u256(ctx.handle, d_query.ptr if n else None, n, d_train.ptr if m else None, m, train_base,
+                                           d_idx.ptr, d_dist.ptr, mode, float(param), d_keep.ptr, ctypes.byref(cnt)))
+    return cnt.value
+
+
 def knn2_device_batch(ctx: Context, searches) -> None:
     """Several independent searches in ONE launch (``slam_bf_knn2_batch_u256``): ``searches`` is a sequence of
     ``(d_query, n_query, d_train, n_train, d_idx, d_dist[, train_base])`` with device buffers, at most 32 entries.

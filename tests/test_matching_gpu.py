@@ -472,3 +472,55 @@ def test_batched_searches_equal_single_launches_and_the_oracle(gpu_ctx):
         sel = rng.choice(4096, 64, replace=False)
         ridx, rdist = oracle.bf_knn_c(q[sel], t, 2, threads=8)
         assert np.array_equal(idx[sel], ridx) and np.array_equal(dist[sel], rdist)
+
+
+@pytest.mark.parametrize("n,m", [(1, 1), (70, 1), (300, 2), (4096, 4096), (1000, 20000), (777, 70000), (8192, 65536)])
+def test_selection_fused_into_the_search_equals_the_two_step_way(gpu_ctx, n, m):
+    """slam_bf_knn2_select_u256: the search's own decode flags the queries (mode 0: has a neighbour; mode 2: Lowe ratio, BASELINE
+    configs[1]) - same tables, same flags and the same count as search + slam_bf_match_filter and as the oracle, under every
+    kind of plan (one-round grids, one block per chunk, queue plans with both exchanges, several queries per lane)."""
+    import ctypes
+
+    import slamhip
+    from oracle import oracle
+
+    ctx = gpu_ctx
+    rng = np.random.default_rng(n + m)
+    q = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    t = rng.integers(0, 256, (m, 32), dtype=np.uint8)
+    k = min(n, m, 50)
+    t[rng.choice(m, k, replace=False)] = q[rng.choice(n, k, replace=False)]        # true matches: the ratio test keeps something
+    ridx, rdist = oracle.bf_knn_c(q, t, 2, threads=8)
+    dq, dt = slamhip.DeviceDescriptors(ctx, q), slamhip.DeviceDescriptors(ctx, t)
+    tab, keep, keep2 = slamhip.Top2Table(ctx, n), ctx.malloc(n + 64), ctx.malloc(n + 64)
+    try:
+        for knobs in (dict(), dict(queue=-1), dict(queue=1, merge=1), dict(queue=1, merge=-1), dict(R=2), dict(R=8), dict(feed=-1)):
+            ctx.set_tuning(**knobs)
+            for mode, param in ((0, 0.0), (2, 0.75), (2, 0.9), (2, 1.0), (2, 0.0)):
+                got = slamhip.knn2_select_device(ctx, dq.buf, n, dt.buf, m, tab.idx, tab.dist, keep, mode, param)
+                idx, dist = tab.download()
+                assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist), (knobs, mode)
+                flags = keep.download(np.uint8, (n,))
+                want = oracle.bf_ratio_c(ridx, rdist, param).astype(np.uint8) if mode == 2 else (ridx[:, 0] >= 0).astype(np.uint8)
+                assert np.array_equal(flags, want) and got == int(want.sum()), (knobs, mode, param, got, int(want.sum()))
+                cnt, mind = ctypes.c_int64(0), ctypes.c_int32(0)          # the two-step way on the same tables
+                assert ctx.lib.slam_bf_match_filter(ctx.handle, tab.idx.ptr, tab.dist.ptr, n, mode, param, keep2.ptr, ctypes.byref(cnt),
+                                                    ctypes.byref(mind)) == 0
+                assert cnt.value == got and np.array_equal(keep2.download(np.uint8, (n,)), flags)
+            assert ctx.state_dirty() == 0
+    finally:
+        ctx.set_tuning()
+        for o in (tab, dq, dt, keep, keep2):
+            o.free()
+    # no train rows: nothing is kept; a bad mode is refused
+    e = slamhip.DeviceDescriptors(ctx, np.zeros((0, 32), np.uint8))
+    dq = slamhip.DeviceDescriptors(ctx, q)
+    tab, keep = slamhip.Top2Table(ctx, n), ctx.malloc(n + 64)
+    try:
+        assert slamhip.knn2_select_device(ctx, dq.buf, n, e.buf, 0, tab.idx, tab.dist, keep, 2, 0.75) == 0
+        assert not keep.download(np.uint8, (n,)).any()
+        with pytest.raises(slamhip.SlamHipError):
+            slamhip.knn2_select_device(ctx, dq.buf, n, dq.buf, n, tab.idx, tab.dist, keep, 1, 30.0)
+    finally:
+        for o in (tab, dq, e, keep):
+            o.free()
