@@ -107,7 +107,8 @@ def cpu_baseline(query: np.ndarray, train: np.ndarray) -> dict:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         pass
-    cores = min(cores, 16)                          # the one-GPU box's CPU share
+    available = cores
+    cores = min(cores, 16)                          # the one-GPU box's CPU share (said in the line when it bites: cores_capped_from)
     # 65536 x 65536: the whole workload (~15-20 core-seconds of popcnt per pass); loop closure: the first 65536 query rows
     # against the whole 2^20-row collection (the same cost per query row as the full job, 1/16 of its rows)
     rows = min(query.shape[0], max(4096, int(2 ** 36 // max(train.shape[0], 1))))
@@ -136,7 +137,8 @@ def cpu_baseline(query: np.ndarray, train: np.ndarray) -> dict:
     t0 = time.perf_counter()
     oracle.bf_knn_c(q[:one_rows], train, 2, threads=1)
     dt1 = time.perf_counter() - t0
-    return {"value": rows * train.shape[0] / dt, "unit": "pairs/s", "cores": cores, "kind": "port", "cv2": cv2_out,
+    return {"value": rows * train.shape[0] / dt, "unit": "pairs/s", "cores": cores, "cores_capped_from": available if available > cores else None,
+            "kind": "port", "cv2": cv2_out,
             "single_thread": {"value": one_rows * train.shape[0] / dt1, "unit": "pairs/s",
                               "sample": f"first {one_rows} query rows x {train.shape[0]}, {dt1:.2f} s"},
             "sample": f"{'all' if rows == query.shape[0] else 'the first'} {rows} query rows x {train.shape[0]} train rows (the same arrays), oracle/bf_hamming_oracle.c "

@@ -38,7 +38,7 @@ IMGIDX_SHIFT = 18  # OpenCV matchers.cpp: index = imgIdx << 18 | trainIdx
 
 def build(force: bool = False) -> str:
     """Compile liboracle.so with gcc (used by __graft_entry__.build())."""
-    srcs = [os.path.join(_HERE, f) for f in ("bf_hamming_oracle.c", "reproj_oracle.c", "pose_lm_oracle.c")]
+    srcs = sorted(os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h")) or f == "Makefile")   # every source there is
     stale = force or not os.path.exists(_LIB_PATH) or any(
         os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs
     )

@@ -376,3 +376,26 @@ def test_busy_one_launch_ba_falls_back_to_the_per_phase_kernels(monkeypatch):
         assert invalid.lib.calls == 1 and len(fell_back) == 2            # a caller error is not retried
     finally:
         L._lib = old
+
+
+def test_generated_scan_header_is_what_its_generator_writes(tmp_path):
+    """csrc/bf_scan_sgpr.h (889 lines of straight-line gfx950 assembly) is GENERATED and committed: the committed file must be
+    exactly what tools/gen_scan_asm.py writes today, so neither can drift without the other."""
+    import sys
+
+    out = tmp_path / "bf_scan_sgpr.h"
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_scan_asm.py"), str(out)], check=True, capture_output=True)
+    committed = open(os.path.join(ROOT, "slam-experiments_amd", "csrc", "bf_scan_sgpr.h")).read()
+    assert out.read_text() == committed, "bf_scan_sgpr.h differs from the generator's output: rerun tools/gen_scan_asm.py (or fix it)"
+
+
+def test_oracle_build_watches_every_source():
+    """oracle.build() rebuilds liboracle.so when ANY of its sources is newer (round 3 missed ba_lm_oracle.c)."""
+    import inspect
+
+    from oracle import oracle
+
+    src = inspect.getsource(oracle.build)
+    assert "listdir" in src and "ba_lm_oracle.c" not in src          # no hand-kept list to forget a file in
+    names = {f for f in os.listdir(os.path.join(ROOT, "oracle")) if f.endswith(".c")}
+    assert {"ba_lm_oracle.c", "bf_hamming_oracle.c", "pose_lm_oracle.c", "reproj_oracle.c"} <= names

@@ -4,11 +4,13 @@ as one asm statement (macro SLAM_SCAN_GROUPS_ASM).  The statement is ~460 lines 
 fixed register plan, so it is generated rather than typed; the output is committed and compiled as is.
 
     python tools/gen_scan_asm.py            (rewrites the header; `git diff` shows what changed)
+    python tools/gen_scan_asm.py PATH       (writes it to PATH: tests/test_abi_and_host_cpu.py holds the committed header to it)
 """
 import os
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OUT = os.path.join(ROOT, "slam-experiments_amd", "csrc", "bf_scan_sgpr.h")
+OUT = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "slam-experiments_amd", "csrc", "bf_scan_sgpr.h")   # (a path argument: write there)
 G = 4                                   # rows per SGPR set (two sets alternate)
 ACC, TMP, VM, VKEY = 32, 48, 56, 57     # VGPRs: 16 accumulators, 8 temporaries, group mask, key
 SA = 36                                 # SGPR set A = s[36 : 36 + 8G), set B right behind it
@@ -26,7 +28,17 @@ def load_set(base, first_row):
             for k in range(0, G, 2)]
 
 
+PAIRWISE = os.environ.get("SLAM_SCAN_PAIRWISE") == "1"    # experiment: two temporaries, reused pairwise
+
+
 def row(r, sbase):
+    if PAIRWISE:
+        out = []
+        for w in range(0, 8, 2):
+            out += [line("s_setprio 0"), line(f"v_xor_b32 v{TMP}, s{sbase + w}, %[q{w}]"), line(f"v_xor_b32 v{TMP + 1}, s{sbase + w + 1}, %[q{w + 1}]"),
+                    line("s_setprio 2"), line(f"v_bcnt_u32_b32 v{ACC + r}, v{TMP}, " + ("%[init]" if w == 0 else f"v{ACC + r}")),
+                    line(f"v_bcnt_u32_b32 v{ACC + r}, v{TMP + 1}, v{ACC + r}")]
+        return out
     out = [line("s_setprio 0")]
     out += [line(f"v_xor_b32 v{TMP + w}, s{sbase + w}, %[q{w}]") for w in range(8)]
     out += [line("s_setprio 2"), line(f"v_bcnt_u32_b32 v{ACC + r}, v{TMP}, %[init]")]
