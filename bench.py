@@ -98,6 +98,17 @@ def make_descriptors(n: int, seed: int) -> np.ndarray:
     return np.random.default_rng(seed).integers(0, 256, (n, 32), dtype=np.uint8)
 
 
+def launch_plan(ctx, n: int, m: int) -> dict:
+    """The plan the search runs for n x m on this device (slam_bf_plan_info + what only slam_bf_plan_describe tells: whether it is
+    a queue plan - `workers` resident blocks per query block draw the chunks by ticket - and how its workers exchange bounds)."""
+    import slamhip
+
+    plan = ctx.plan_info(n, m)
+    more, _ = slamhip.plan_describe(n, m, num_cu=plan["cus"])
+    plan.update(workers=more["workers"], merge_exchange=more["merge"], resident_blocks_per_cu=more["resident"])
+    return plan
+
+
 def cpu_baseline(query: np.ndarray, train: np.ndarray) -> dict:
     """Oracle (CPU port of the cv2 path) on a bounded sample of the same workload, all host cores."""
     from oracle import oracle
@@ -586,7 +597,7 @@ def main() -> int:
                          n_local=sm.n_local, wall_ms=wall_ms, dev_ms=dev_ms, rank_kernel_ms=rank_kernel_ms, launches=launches,
                          collective=collective, fallback_reason=fallback_reason,
                          rccl_version=None if rccl_version is None else rccl_version.value,
-                         plan=ctx.plan_info(max(sm.n_local, 1), n_train), ok=ok, train_replication=sm.train_replication)
+                         plan=launch_plan(ctx, max(sm.n_local, 1), n_train), ok=ok, train_replication=sm.train_replication)
         if world > 1:
             out["cpu_baseline"] = None
             out["cpu_baseline_note"] = "the CPU leg is timed at N=1 only (same arrays; see the N=1 line)"
