@@ -21,7 +21,7 @@ python3 - "$SRC/bf_hamming.hip" "$TMP/bf_trace.hip" "$TMP/bf_keep.hip" "$TMP/bf_
 import sys
 src = open(sys.argv[1]).read()
 T = '    if (tid == 0 && g_trace) { g_trace[4*(by*(int)gridDim.x+bx)+%d] = wall_clock64(); }\n'
-s = src.replace('    const bool leader = by < lead;\n', T % 0 + '    const bool leader = by < lead;\n', 1)
+s = src.replace('    const bool leader = !QUEUE && by < lead;\n', T % 0 + '    const bool leader = !QUEUE && by < lead;\n', 1)
 s = s.replace('        int buf = 0;\n', '    ' + T % 1 + '        int buf = 0;\n', 1)
 s = s.replace('        bool fresh = true;', T % 1 + '        bool fresh = true;', 1)
 s = s.replace('    // ---- epilogue: merge,', T % 2 + '    // ---- epilogue: merge,', 1)
@@ -31,10 +31,15 @@ s = s.replace('typedef uint32_t u32;', 'typedef uint32_t u32;\n__device__ unsign
               '{ return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &p, sizeof(p)); }', 1)
 assert s.count('g_trace[') == 5, "trace hooks did not apply: the kernel source changed"
 open(sys.argv[2], 'w').write(s)
-old = '__hip_atomic_store(&st.bound[qi], SLAM_BOUND_IDLE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);'
-assert src.count(old) == 1, "keep-bound hook did not apply: the kernel source changed"
-open(sys.argv[3], 'w').write(src.replace(old, '__hip_atomic_store(&st.bound[qi], k2 == SLAM_KEY_NONE ? SLAM_BOUND_IDLE : '
-                                              '(k2 >> SLAM_KEY_IDX_BITS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);'))
+old = 'if (!merging) __hip_atomic_store(&st.bound[qi], SLAM_BOUND_IDLE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);'
+old2 = '__hip_atomic_store(&st.best[qi], ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);'
+assert src.count(old) == 1 and src.count(old2) == 1, "keep-bound hooks did not apply: the kernel source changed"
+# bound form: the final 2nd-best distance stays in bound[]; merge form: the final pair stays in best[] (folding the same rows
+# again changes nothing) - either way the next search of the same inputs starts every block at its final threshold
+k = src.replace(old, 'if (!merging) __hip_atomic_store(&st.bound[qi], k2 == SLAM_KEY_NONE ? SLAM_BOUND_IDLE : '
+                     '(k2 >> SLAM_KEY_IDX_BITS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);')
+k = k.replace(old2, 'if (!merging) ' + old2)
+open(sys.argv[3], 'w').write(k)
 g = '    if (__builtin_expect(__ballot((int)m >= 0) != 0ull, 0)) {\n'
 r = '            if (U > 1 && __ballot((int)mu >= 0) == 0ull) continue;\n'
 assert src.count(g) == 1 and src.count(r) == 1, "count hooks did not apply: the kernel source changed"
@@ -47,7 +52,7 @@ open(sys.argv[4], 'w').write(c)
 # cycle stamps: one asm statement per stamp (s_memtime + s_memrealtime + the wait), wave 0 lane 0 stores both
 C = ('    if (g_cyc) { unsigned long long c_, r_; asm volatile("s_memtime %%0\\n\\ts_memrealtime %%1\\n\\ts_waitcnt lgkmcnt(0)" : "=s"(c_), "=s"(r_) :: "memory");\n'
      '        if (tid == 0) { g_cyc[8*(by*(int)gridDim.x+bx)+%d] = c_; g_cyc[8*(by*(int)gridDim.x+bx)+%d] = r_; } }\n')
-y = src.replace('    const bool leader = by < lead;\n', C % (0, 1) + '    const bool leader = by < lead;\n', 1)
+y = src.replace('    const bool leader = !QUEUE && by < lead;\n', C % (0, 1) + '    const bool leader = !QUEUE && by < lead;\n', 1)
 y = y.replace('        int buf = 0;\n', C % (2, 3) + '        int buf = 0;\n', 1)
 y = y.replace('        bool fresh = true;', C % (2, 3) + '        bool fresh = true;', 1)
 y = y.replace('    // ---- epilogue: merge,', C % (4, 5) + '    // ---- epilogue: merge,', 1)

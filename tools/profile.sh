@@ -8,7 +8,7 @@
 # the program itself follows `--` (python3 bench.py ...): no env / bash -c hop between rocprofv3 and the GPU process.
 set -uo pipefail
 cd "$(dirname "$0")/.."
-ROUND="${ROUND:-r03}"
+ROUND="${ROUND:-r04}"
 OUT=gpurun_out/$ROUND
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -31,6 +31,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_long -o stats
 # BASELINE configs[1] (4096 x 4096) and the 1/8 shard of the headline grid under the same profiler
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_4096 -o stats -- $PY tools/run_search.py 4096x4096 400 > /dev/null 2> $OUT/stats_4096.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_shard -o stats -- $PY tools/run_search.py 8192x65536 200 > /dev/null 2> $OUT/stats_shard.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_shard4 -o stats -- $PY tools/run_search.py 16384x65536 200 > /dev/null 2> $OUT/stats_shard4.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_shard2 -o stats -- $PY tools/run_search.py 32768x65536 200 > /dev/null 2> $OUT/stats_shard2.err
 echo "kernel stats done"
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --output-format csv -d $OUT/sq1 -o sq1 -- $PY $B --no-reproj > /dev/null 2> $OUT/sq1.err
 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY --output-format csv -d $OUT/sq2 -o sq2 -- $PY $B --no-reproj > /dev/null 2> $OUT/sq2.err
@@ -41,6 +43,8 @@ SQ_N=8192 SQ_M=65536 $PY tools/sq_summary.py $OUT/sq_shard > $OUT/sq_counters_sh
 echo "sq counters done"
 bash tools/build_exp.sh > /dev/null 2>&1
 $PY tools/cycle_probe.py 65536x65536 8192x65536 4096x4096 > $OUT/cycles.log 2>&1
+( $PY tools/trace_probe.py 8192x65536; $PY tools/trace_probe.py 65536x65536; $PY tools/trace_probe.py 8192x65536 0 0 0 -1 ) > $OUT/block_timeline.log 2>&1
+$PY tools/ab_time.py slam-experiments_amd/lib/libslamhip.so,tools/exp/libslamhip_keepbound.so 8192x65536 16384x65536 65536x65536 --rounds 3 > $OUT/perfect_bound_ceiling.log 2>&1
 $PY tools/size_probe.py > $OUT/sizes.log 2>&1
 $PY tools/latency.py > $OUT/latency_small_calls.log 2>&1
 $PY tools/fire_probe.py > $OUT/update_path_share.log 2>&1
