@@ -28,17 +28,16 @@
 //     on packed keys (dist << 23 | train index): 2nd = med3, 1st = min, which
 //     keeps OpenCV's (distance asc, index asc) order because keys are unique and
 //     compare lexicographically.
-//   * the train axis is split into chunks (grid.y) so any N fills 256 CUs and
-//     finished waves are replaced until the end.  Chunk boundaries come from a
-//     small table built on the host: leader chunk(s) first, then uniform ones,
-//     then a run of shrinking ones so that the blocks dispatched last have the
-//     least to do.  Blocks that scan different chunks for the same queries
-//     exchange their 2nd-best distance through a per-query bound in global
-//     memory (atomicMin + relaxed agent-scope load per 256 rows, more often in a
-//     block's first rows), so a chunk does not start from an infinite threshold;
-//     a stale bound is only looser, never wrong.  The leader blocks (lowest
-//     grid.y, dispatched first) publish the exact 2nd-best distance of
-//     everything merged so far when they finish.
+//   * the train axis is split into chunks so any N fills 256 CUs.  Chunk boundaries come from a small table built on
+//     the host (make_plan_core).  Large searches run a QUEUE plan (round 4): as many worker blocks per query block as are
+//     resident at once, whose waves draw the chunks by ticket (one returning atomic add per chunk) and keep their top-2
+//     from chunk to chunk; the chunks shrink towards the end of the queue, so all waves run out of work together, and
+//     nobody waits for anybody.  Other shapes run one block per chunk (grid.y = chunks): leader chunk(s) first, uniform
+//     ones, then a run of shrinking ones so that the blocks dispatched last have the least to do.
+//   * blocks that scan different chunks for the same queries tighten each other's thresholds once per chunk / 256 rows:
+//     through a per-query bound in global memory (returning atomicMin + relaxed agent-scope load; a stale bound is only
+//     looser, never wrong), or - queue plans with many workers per query - by folding their pair into the result slot
+//     and reading its 2nd key back: the exact 2nd-best distance of everything folded in so far (share_union).
 //   * a chunk that starts before anybody has published a bound for its queries
 //     (the first dispatch round of a big search, every block of a small one)
 //     folds its first rows - 128, or the whole chunk of a small train set - into
@@ -48,9 +47,11 @@
 //   * every block folds its top-2 into a per-query 64-bit slot with two 32-bit
 //     atomic minima (1st key; then the loser or the own 2nd key); the last
 //     block to arrive for a query block (agent-scope ticket, no release fence:
-//     every contribution is a returned memory-side atomic) decodes the slots to
-//     (int32 idx, int32 dist) and restores the merge state, so a call is ONE
-//     kernel: no memset, no partial tables, no merge kernel.
+//     every contribution is a returned memory-side atomic; pinned on the ISA by
+//     tests/test_isa_handoff_cpu.py) decodes the slots to (int32 idx, int32 dist),
+//     makes the selections that need no reduction over the queries (bf_select) and
+//     restores the merge state, so a call is ONE kernel: no memset, no partial
+//     tables, no merge kernel.
 //   * several independent searches can share one launch (bf_top2_batch_kernel).
 #include "internal.h"
 #include "bf_scan_sgpr.h"
@@ -213,9 +214,9 @@ __device__ __forceinline__ void insert_rows(const u32 (&acc)[U][R], u32 first_tr
 // 8192 x 65536 212 -> 222 us, 2000 x 2000 21 -> 33 us.)
 // gk[r] keeps the last bound seen (an upper bound of the final 2nd-best distance for good: bound[] only decreases
 // during a launch); the epilogue uses it to skip merges that cannot matter, without another round trip.
-#ifndef SLAM_EXP_SHARE
-#define SLAM_EXP_SHARE 2
-#endif
+// (Forms measured against each other in round 4, profiles/r04_ab_queue.log "share_bound forms": the returning atomic waited for
+// on the spot, round 3's load + no-return atomic, and this one with and without the "nothing before a 2nd neighbour" rule - all
+// within 1 % of each other; this is the one whose writes are known to be complete.)
 template <int R>
 __device__ __forceinline__ void share_bound(u32* __restrict__ bound, int qbase, int N, const u32 (&b2)[R],
                                             u32 (&init)[R], u32 (&gk)[R], u32 (&pend)[R]) {
@@ -224,14 +225,6 @@ __device__ __forceinline__ void share_bound(u32* __restrict__ bound, int qbase, 
         const int qi = qbase + r * 64;
         if (qi < N) {
             const u32 own = b2[r] >> SLAM_KEY_IDX_BITS;
-#if SLAM_EXP_SHARE == 0
-            u32 g;
-            if (own < gk[r] && own <= 256u) g = min(atomicMin(&bound[qi], own), own);   // what bound[] holds now
-            else g = __hip_atomic_load(&bound[qi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#elif SLAM_EXP_SHARE == 1
-            const u32 g = __hip_atomic_load(&bound[qi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (own < g) atomicMin(&bound[qi], own);
-#else
             // The bound is READ with a relaxed agent-scope load.  A lane whose own 2nd-best beats it publishes it with an
             // atomic minimum in the RETURNING form, whose value nobody waits for here: it is parked in pend[] and consumed
             // at the lane's next exchange or in front of the arrival ticket (vector-memory operations return in issue
@@ -240,14 +233,9 @@ __device__ __forceinline__ void share_bound(u32* __restrict__ bound, int qbase, 
             // arriver's reset (a no-return atomic is only known to have been sent).
             asm volatile("" ::"v"(pend[r]));
             const u32 g = __hip_atomic_load(&bound[qi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#if SLAM_EXP_SHARE == 2
             // Nothing is published while the lane has no 2nd neighbour yet (own = 511): a block that starts must still see
             // "nobody has published" (SLAM_BOUND_IDLE) then.
             if (own < g && own <= 256u) pend[r] = atomicMin(&bound[qi], own);
-#else
-            if (own < g) pend[r] = atomicMin(&bound[qi], own);
-#endif
-#endif
             gk[r] = g;
             init[r] = SLAM_ACC_BIAS - min(own, g + 1);
         }
@@ -418,38 +406,25 @@ __device__ __forceinline__ void bf_top2_block(const uint4* __restrict__ q, int N
         const char* tbytes = (const char*)t;
         constexpr bool queue = QUEUE;
         u32* const cursor = st.cursor + (size_t)(4 * bx + wave) * SLAM_CURSOR_STRIDE;
-        // One round trip per chunk: a queue worker draws its tickets ONE CHUNK AHEAD - the draw for the next chunk and the
-        // touch of this chunk's first lines are issued, then the bound exchange, whose wait covers both; what a wave holds
-        // back that way is one chunk from the shrinking end of the queue.  (Nothing but the one touch of the rows behind
-        // the current stretch may be in flight when a scan statement starts: with a second vector load outstanding the
-        // compiler puts an s_waitcnt vmcnt(0) in front of the statement, i.e. a memory round trip in front of every
-        // stretch - 152 -> 157 us on the 1/8 shard, profiles/r04_ab_queue.log.)
+        // One round trip per chunk: a queue worker draws its next ticket right BEHIND a chunk (not a chunk ahead: a wave that
+        // sits on a drawn chunk while it scans another keeps it from a wave that has run dry - tickets one chunk ahead
+        // measured 1045 against 1022 us at 64k x 64k, 534 against 522 at 32768 x 65536) and resolves it behind the bound
+        // exchange of the next one, whose wait covers the draw; a block plan touches its chunk's first lines in front of the
+        // exchange instead (its chunk is known from blockIdx).  Forms measured: profiles/r04_ab_queue.log "queue loop forms".
+        // (Nothing but the one touch of the rows behind the current stretch may be in flight when a scan statement starts:
+        // with a second vector load outstanding the compiler puts an s_waitcnt vmcnt(0) in front of the statement.)
         auto draw = [&]() -> u32 {
             u32 v = 0;
             if (lane == 0) v = __hip_atomic_fetch_add(cursor, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return v;
         };
-#ifndef SLAM_EXP_QLOOP
-#define SLAM_EXP_QLOOP 5
-#endif
         int ci = by;
         u32 ticket = 0;
-        if (queue) {
-            ticket = draw();
-#if SLAM_EXP_QLOOP == 3
-            ci = __builtin_amdgcn_readfirstlane(ticket);
-#endif
-        }
+        if (queue) ticket = draw();
         bool fresh = true;                              // the wave has no threshold of its own yet (its first chunk)
         while (true) {
-#if SLAM_EXP_QLOOP == 3
-            if (queue && ci >= nchunks) break;
-            const int c0 = uni ? ci * uni : tbl[ci];
-            const int c1 = uni ? min(M, c0 + uni) : tbl[ci + 1];
-#else
             int c0 = 0, c1 = 0;
             if (!queue) { c0 = uni ? ci * uni : tbl[ci]; c1 = uni ? min(M, c0 + uni) : tbl[ci + 1]; }
-#endif
             auto touch = [&](int first) -> u32 {
                 // block plans: the four waves of a block share a chunk, each touches a quarter of the lines; queue plans:
                 // every wave has a chunk of its own and touches all 64 lines
@@ -458,27 +433,17 @@ __device__ __forceinline__ void bf_top2_block(const uint4* __restrict__ q, int N
                 if ((queue || lane < 16) && off < (long long)c1 * SLAM_DESC_BYTES) v = *(const u32*)(tbytes + off);
                 return v;
             };
-#if SLAM_EXP_QLOOP == 3
-            u32 warm = touch(c0);
-            if (!nobound) share();
-            asm volatile("" ::"v"(warm));                  // the chunk's first lines are there
-#else
             u32 warm = 0;
             if (!queue) warm = touch(c0);
             if (!nobound) share();
             if (queue) {
-                ci = __builtin_amdgcn_readfirstlane(ticket);
+                ci = __builtin_amdgcn_readfirstlane(ticket);      // drawn behind the previous chunk; its wait was the exchange's
                 if (ci >= nchunks) break;
                 c0 = tbl[ci];
                 c1 = tbl[ci + 1];
-#if SLAM_EXP_QLOOP == 4
-                warm = touch(c0);
-#else
-                if (fresh) warm = touch(c0);
-#endif
+                if (fresh) warm = touch(c0);                     // later chunks: the XCD's L2 has seen the train set by then
             }
-            asm volatile("" ::"v"(warm));
-#endif
+            asm volatile("" ::"v"(warm));                        // the chunk's first lines are there: the scan starts right away
             int row = c0;
             bool is_cold = fresh && cold >= 16 && (nobound || nobody_published());
             bool shared = true;                            // the exchange in front of the chunk's first stretch is done
@@ -515,9 +480,6 @@ __device__ __forceinline__ void bf_top2_block(const uint4* __restrict__ q, int N
             if (!queue) break;
             fresh = false;
             ticket = draw();
-#if SLAM_EXP_QLOOP == 3
-            ci = __builtin_amdgcn_readfirstlane(ticket);
-#endif
         }
     } else {
         const int t0 = uni ? by * uni : tbl[by];
