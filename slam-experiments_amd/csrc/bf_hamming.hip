@@ -1252,8 +1252,12 @@ static int bf_pass(slam_ctx* ctx, const void* d_query, int64_t N, const void* d_
     if (workers) {
         // the plan counts on SLAM_BF_RESIDENT blocks per CU; a build or device that holds fewer gets fewer workers (the
         // table is the same: the waves simply draw more tickets each), never a second dispatch round of idle workers
-        int occ = 0;
-        SLAM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, bf_top2_kernel<1, true, true>, 256, 0));
+        static int occ = 0;                      // a property of the kernel and the architecture: asked once per process
+        if (!occ) {
+            int o = 0;
+            SLAM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, bf_top2_kernel<1, true, true>, 256, 0));
+            occ = o > 0 ? o : SLAM_BF_RESIDENT;
+        }
         const int64_t fit = (int64_t)ctx->num_cu * occ / p.qblocks;
         if (fit >= 1 && fit < workers) workers = (int)fit;
     }
