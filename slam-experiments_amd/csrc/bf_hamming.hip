@@ -645,14 +645,16 @@ __device__ __forceinline__ void bf_top2_block(const uint4* __restrict__ q, int N
     //       the block barrier, then ONE lane's relaxed agent-scope ticket - the guide's hand-off table, first row: "an
     //       agent-scope atomic add ... after every storing wave's vmcnt(0) wait ... the workgroup whose add came last, told by
     //       the value its add returned";
-    //   (3) the block that draws the last ticket invalidates its L1 (agent acquire, kept as cheap insurance: it runs once per
-    //       query block), passes a barrier and reads the slots with sc1 loads ("loads, all sc1" in that table; the payload
-    //       being atomics rather than sc1 stores is the guide's "{8-B agent atomics both sides}" form).
+    //   (3) the block that draws the last ticket passes a barrier and TAKES the slots with returning 8-byte atomic exchanges
+    //       (which also put them back to idle): agent-scope atomics on BOTH sides of the hand-off - the guide's "{8-B agent
+    //       atomics both sides}" form - so no load is involved that an L1 or an XCD's L2 could serve, and no acquire fence is
+    //       needed (round 3 read the slots with sc1 loads behind a buffer_inv sc1: 4096 x 4096 16.2 -> 15.6 us without it, other
+    //       sizes equal; profiles/r04_ab_queue.log "swap").
     // The G16 counter recipe has an agent-scope RELEASE fence (buffer_wbl2 sc1) in front of the ticket; it writes back dirty L2
     // lines, of which this hand-off has none, and cost 1.7 us on the critical path of every block: 4096 x 4096 18.4 -> 16.7 us,
     // 2000 x 2000 10.7 -> 9.4 us, the 1/8 shard 159.9 -> 154.8 us without it (profiles/r03_ab_cold_start.log).
     // tests/test_isa_handoff_cpu.py holds every build to (1)-(3) on the disassembly (return forms, wait and barrier in front
-    // of the ticket, invalidate + sc1 loads behind it; profiles/r04_isa_handoff_excerpt.txt), and every search leaves the
+    // of the ticket, returning exchanges behind it; profiles/r04_isa_handoff_excerpt.txt), and every search leaves the
     // whole state idle, which the GPU tests assert on the state itself (slam_bf_state_dirty).  Placement-independent: nothing
     // relies on which XCD a block runs on.
     if (!merging) {
@@ -665,8 +667,7 @@ __device__ __forceinline__ void bf_top2_block(const uint4* __restrict__ q, int N
         const u32 ticket = __hip_atomic_fetch_add(&st.arrivals[bx], 1u, __ATOMIC_RELAXED,
                                                   __HIP_MEMORY_SCOPE_AGENT);
         s_last = ticket == (u32)S - 1 ? 1u : 0u;
-        if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("" ::"s"(ticket));                 // (the ticket is back: its value was just used)
     }
     __syncthreads();
     if (!s_last) return;
@@ -675,8 +676,9 @@ __device__ __forceinline__ void bf_top2_block(const uint4* __restrict__ q, int N
         const int qi = qbase + r * 64;
         int kept = 0;
         if (qi < N) {
-            // every contribution was made by an agent-scope atomic; read it back the same way (never from L1)
-            const unsigned long long v = __hip_atomic_load(&st.best[qi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // every contribution was made by an agent-scope atomic; it is taken - and the slot put back to idle for the next
+            // launch - by one more (all other blocks are done with these queries)
+            const unsigned long long v = __hip_atomic_exchange(&st.best[qi], ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const u32 k1 = (u32)(v >> 32), k2 = (u32)v;
             int2 oi, od;
             oi.x = k1 == SLAM_KEY_NONE ? SLAM_NO_MATCH_IDX : (int)(k1 & SLAM_KEY_IDX_MASK) + train_base;
@@ -691,8 +693,6 @@ __device__ __forceinline__ void bf_top2_block(const uint4* __restrict__ q, int N
                 sel.keep[qi] = k ? 1 : 0;
                 kept = k ? 1 : 0;
             }
-            // restore the between-launch invariant for these queries (all other blocks are done with them)
-            __hip_atomic_store(&st.best[qi], ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (!merging) __hip_atomic_store(&st.bound[qi], SLAM_BOUND_IDLE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (sel.keep && qi - lane < N) {                   // (wave-uniform: the group's first query exists)

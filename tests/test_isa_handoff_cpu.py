@@ -9,8 +9,9 @@ GPU needed) and checks, in every kernel that contains the epilogue:
      returned value is what tells the wave that the minimum has been taken at the memory side;
   2. the arrival ticket is a returning ``global_atomic_add``; in front of it, in this order and with no vector-memory
      instruction in between: ``s_waitcnt vmcnt(0)`` (every wave has its atomics back), ``s_barrier``;
-  3. the last arriver invalidates (``buffer_inv sc1``), waits (``s_waitcnt vmcnt(0)``), passes a barrier, and the first loads
-     behind it - the result slots - are ``sc1`` loads (never served from this CU's L1).
+  3. behind the ticket and a barrier, the last arriver TAKES the result slots with returning 8-byte atomic exchanges
+     (``global_atomic_swap_x2 ... sc0``: agent-scope atomics on both sides of the hand-off, no load that a cache could serve;
+     the exchange also puts the slot back to idle).
 
 A compiler upgrade that drops a return form or moves a wait fails here instead of racing silently.
 The epilogue of bf_top2_kernel<1, true, true> as built for round 4 is kept in profiles/r04_isa_handoff_excerpt.txt."""
@@ -71,20 +72,31 @@ def test_every_merge_atomic_returns(kernels):
         assert not [i for i in ins if i.startswith(("flat_atomic", "global_atomic_cmpswap"))], name
 
 
-def test_ticket_sits_behind_wait_and_barrier_and_the_last_arriver_reads_past_l1(kernels):
+def test_ticket_sits_behind_wait_and_barrier_and_the_last_arriver_reads_with_atomics(kernels):
     checked = 0
     for name, ins in kernels.items():
-        inv = [k for k, i in enumerate(ins) if i.startswith("buffer_inv sc1")]
-        assert inv, f"{name}: no agent-scope invalidate - the last arriver's acquire is gone"
+        swaps = [k for k, i in enumerate(ins) if i.startswith("global_atomic_swap_x2")]
+        assert swaps, f"{name}: the last arriver no longer takes the result slots with an atomic exchange"
         assert not [i for i in ins if i.startswith("buffer_wbl2")], f"{name}: a release fence is back: say so in bf_hamming.hip"
-        for at in inv:
-            # backwards: the ticket
-            k = at
+        tickets = set()
+        for at in swaps:
+            assert " sc0" in ins[at], f"{name}: the exchange must return the slot"
+            # backwards from the exchange: a barrier (the block learns whether it is the last arriver), then the ticket
+            k = at - 1
+            seen_barrier = later_query = False
             while k >= 0 and not ins[k].startswith("global_atomic_add"):
-                assert not VMEM.match(ins[k]) , f"{name}: {ins[k]} between the ticket and the invalidate"
+                if ins[k].startswith(("global_atomic_swap_x2", "global_store")):
+                    later_query = True                     # several queries per lane: one ticket, R exchanges (each followed by the
+                    break                                  # stores of its decode) - the first one is checked, and every kernel has one
+                assert not VMEM.match(ins[k]), f"{name}: {ins[k]} between the ticket and the exchange"
+                seen_barrier = seen_barrier or ins[k].startswith("s_barrier")
                 k -= 1
-            assert k >= 0 and " sc0" in ins[k], f"{name}: the arrival ticket must return its value"
+            if later_query:
+                continue
+            assert k >= 0 and " sc0" in ins[k] and seen_barrier, f"{name}: no returning ticket + barrier in front of the exchange"
             ticket = k
+            assert ticket not in tickets
+            tickets.add(ticket)
             # backwards from the ticket: barrier, then the wait, with no vector-memory instruction in between
             k = ticket - 1
             seen_barrier = False
@@ -98,17 +110,8 @@ def test_ticket_sits_behind_wait_and_barrier_and_the_last_arriver_reads_past_l1(
                     assert not VMEM.match(i), f"{name}: {i} between the waves' wait and the ticket"
                 k -= 1
             assert k >= 0 and seen_barrier, f"{name}: no s_waitcnt vmcnt(0) + s_barrier in front of the ticket"
-            # forwards from the invalidate: wait, barrier, sc1 loads
-            k = at + 1
-            waited = barrier = False
-            while k < len(ins) and not ins[k].startswith(("global_load", "buffer_load", "flat_load")):   # (block layout may put a store first)
-                waited = waited or (ins[k].startswith("s_waitcnt") and "vmcnt(0)" in ins[k])
-                barrier = barrier or (ins[k].startswith("s_barrier") and waited)
-                k += 1
-            assert waited and barrier, f"{name}: the invalidate is not waited for in front of the barrier"
-            assert k < len(ins) and ins[k].startswith("global_load_dwordx2") and ins[k].rstrip().endswith("sc1"), \
-                f"{name}: the result slots must be read by sc1 loads, found {ins[k] if k < len(ins) else None}"
             checked += 1
+        assert tickets, f"{name}: no exchange that follows its ticket directly"
     assert checked >= 7                                  # the batch kernel carries the epilogue twice (both feeds)
 
 
