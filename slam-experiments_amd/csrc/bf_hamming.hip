@@ -422,6 +422,7 @@ __device__ __forceinline__ void bf_top2_block(const uint4* __restrict__ q, int N
         u32 ticket = 0;
         if (queue) ticket = draw();
         bool fresh = true;                              // the wave has no threshold of its own yet (its first chunk)
+        int chunks_done = 0;
         while (true) {
             int c0 = 0, c1 = 0;
             if (!queue) { c0 = uni ? ci * uni : tbl[ci]; c1 = uni ? min(M, c0 + uni) : tbl[ci + 1]; }
@@ -435,7 +436,14 @@ __device__ __forceinline__ void bf_top2_block(const uint4* __restrict__ q, int N
             };
             u32 warm = 0;
             if (!queue) warm = touch(c0);
-            if (!nobound) share();
+            // Queue workers that exchange through bound[] (few workers per query: each has thousands of rows of its own) do so
+            // on their first four chunks and then on every 4th: the reads are agent-scope loads of lines that the publishing
+            // atomics keep dropping from the L2s, i.e. fabric traffic for nothing once the thresholds have settled (64k x 64k:
+            // FETCH_SIZE 49.0 -> 34.3 MB raw per launch at 1018.7 -> 1016.4 us; every 16th: 27.9 MB but 1024.5 us;
+            // profiles/r04_ab_queue.log "exchange").  The merge form keeps every chunk (the shard is where thresholds matter).
+            const bool exchange = !queue || merging || chunks_done < 4 || (chunks_done & 3) == 0;
+            chunks_done++;
+            if (!nobound && exchange) share();
             if (queue) {
                 ci = __builtin_amdgcn_readfirstlane(ticket);      // drawn behind the previous chunk; its wait was the exchange's
                 if (ci >= nchunks) break;

@@ -8,6 +8,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "slam-experiments_amd"))
 import slamhip  # noqa: E402
+from slamhip import _lib  # noqa: E402
+
+if os.environ.get("SLAM_LIB"):                            # another build of the library (tools/exp/...)
+    _lib.LIB_PATH = os.path.abspath(os.environ["SLAM_LIB"])
 
 n, m = (int(v) for v in sys.argv[1].split("x"))
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 30
