@@ -22,6 +22,7 @@
 //   ba_pair_kernel    one block per (k1 <= k2)   : the S block (over k1's obs list, looking k2's up)
 //   ba_backsub_kernel one thread per point       : dl
 #include "internal.h"
+#include <atomic>
 #include <math.h>
 
 #define BA_THREADS 256
@@ -1307,11 +1308,13 @@ extern "C" int slam_ba_optimize_f64(slam_ctx* ctx, int64_t K, int64_t L, int64_t
     a.delta = huber_delta;
     // Every workgroup has to be resident at once (hand-made grid barriers): refuse what this device could never hold; what
     // it cannot hold RIGHT NOW (other work on the compute units) is found out by the barriers themselves, in bounded time.
-    static int blocks_per_cu = 0;                  // a property of the kernel and the architecture: computed once
+    static std::atomic<int> per_cu_once{0};        // a property of the kernel and the architecture: computed once per process
+    int blocks_per_cu = per_cu_once.load(std::memory_order_relaxed);
     if (!blocks_per_cu) {
         int occ = 0;
         SLAM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, ba_lm_grid_kernel, BA_THREADS, 0));
         blocks_per_cu = occ > 0 ? occ : -1;
+        per_cu_once.store(blocks_per_cu, std::memory_order_relaxed);
     }
     if (blocks_per_cu < 0 || (int64_t)blocks_per_cu * ctx->num_cu < a.nblocks)
         return slam_set_error(SLAM_ERR_BUSY, "slam_ba_optimize_f64: %d workgroups cannot be resident at once on %d compute units",

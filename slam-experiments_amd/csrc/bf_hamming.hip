@@ -57,6 +57,7 @@
 #include "bf_scan_sgpr.h"
 #include <stdio.h>
 #include <vector>
+#include <atomic>
 
 typedef uint32_t u32;
 
@@ -394,8 +395,8 @@ __device__ __forceinline__ void bf_top2_block(const uint4* __restrict__ q, int N
         //
         // QUEUE plans (nchunks > 0; round 4): grid.y is not the number of chunks but the number of WORKER blocks per query
         // block - as many as are resident at once - and every wave draws its chunks itself: a ticket from the cursor of
-        // its query wave (one returning agent-scope atomic add, issued beside the bound exchange of the chunk, so it adds
-        // no round trip), chunk = tbl[ticket] .. tbl[ticket + 1], until the tickets run out.  A wave keeps its top-2 and
+        // its query wave (one returning agent-scope atomic add, issued behind a chunk and waited for together with the
+        // exchange in front of the next), chunk = tbl[ticket] .. tbl[ticket + 1], until the tickets run out.  A wave keeps its top-2 and
         // its threshold from chunk to chunk: ONE start without a threshold, ONE merge and ONE arrival per worker instead
         // of one per chunk, no dispatch of a new block between chunks, and the waves of a SIMD stay busy until the queue
         // of their query wave is empty - the chunks shrink towards its end (make_plan_core), so they all run out of work
@@ -1260,11 +1261,13 @@ static int bf_pass(slam_ctx* ctx, const void* d_query, int64_t N, const void* d_
     if (workers) {
         // the plan counts on SLAM_BF_RESIDENT blocks per CU; a build or device that holds fewer gets fewer workers (the
         // table is the same: the waves simply draw more tickets each), never a second dispatch round of idle workers
-        static int occ = 0;                      // a property of the kernel and the architecture: asked once per process
+        static std::atomic<int> occ_once{0};     // a property of the kernel and the architecture: asked once per process
+        int occ = occ_once.load(std::memory_order_relaxed);
         if (!occ) {
             int o = 0;
             SLAM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, bf_top2_kernel<1, true, true>, 256, 0));
             occ = o > 0 ? o : SLAM_BF_RESIDENT;
+            occ_once.store(occ, std::memory_order_relaxed);
         }
         const int64_t fit = (int64_t)ctx->num_cu * occ / p.qblocks;
         if (fit >= 1 && fit < workers) workers = (int)fit;

@@ -22,6 +22,11 @@ echo "hbm counters done: $(grep -c traffic_bytes $OUT/hbm_counters.json) kernels
 
 $PY bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err
 echo "bench done: $(cut -c1-200 $OUT/bench_n1.json)"
+# PROFILE_ONLY=hbm: the counters and the line that reads them only (after an edit that touched a kernel source's text)
+if [ "${PROFILE_ONLY:-}" = "hbm" ]; then
+    rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_default -o stats -- $PY bench.py > $OUT/bench_default_under_rocprof.json 2> $OUT/stats_default.err
+    exit 0
+fi
 $PY bench.py --workload loop-closure --steps 10 --warmup 1 > $OUT/bench_loop_closure_n1.json 2> $OUT/bench_loop_closure_n1.err
 echo "loop closure done: $(cut -c1-160 $OUT/bench_loop_closure_n1.json)"
 SLAM_BENCH_SINGLE_DEVICE=1 SLAM_BENCH_COLLECTIVE=p2p $PY bench.py --gpus 2 --workload loop-closure --steps 3 --warmup 0 > $OUT/bench_loop_closure_2ranks_one_gpu.json 2> $OUT/bench_loop_closure_2ranks_one_gpu.err
