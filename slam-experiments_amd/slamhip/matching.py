@@ -117,6 +117,7 @@ class _MatchOutputs:
         self.rows = 0
         self.cnt = ctypes.c_int64(0)
         self.p_cnt = ctypes.byref(self.cnt)
+        self.reserve(1)                                  # (an empty query side still gets valid pointers and empty slices)
 
     def reserve(self, n: int) -> None:
         if n > self.rows:
