@@ -149,6 +149,15 @@ def load() -> ctypes.CDLL:
     return lib
 
 
+def addr(a) -> int:
+    """Address of a C-contiguous numpy array: 0.46 us through the buffer protocol against 1.3-1.4 us for ``a.ctypes.data`` or
+    ``a.__array_interface__`` (a frame-sized ``match()`` is a 5 us kernel; the per-frame host calls pass up to nine pointers)."""
+    try:
+        return ctypes.addressof(ctypes.c_char.from_buffer(a))
+    except (TypeError, ValueError):              # a read-only or empty array has no writable buffer to borrow
+        return a.__array_interface__["data"][0]
+
+
 def check(rc: int) -> None:
     if rc != SLAM_OK:
         msg = load().slam_last_error()

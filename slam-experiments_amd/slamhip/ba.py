@@ -15,7 +15,7 @@ from typing import Optional, Sequence
 
 import numpy as np
 
-from ._lib import SLAM_ERR_INVALID, SlamHipBusy, SlamHipError, check
+from ._lib import SLAM_ERR_INVALID, SlamHipBusy, SlamHipError, addr, check
 from .device import Context, default_context
 from .pose_opt import se3_exp
 from .reproj import ReprojProblem, poses_to_rt12
@@ -280,9 +280,8 @@ def bundle_adjust_one_launch(poses, points, obs_pose_idx, obs_point_idx, meas, i
     Tout, Xout, st = np.empty((K, 12)), np.empty((L, 3)), np.empty(8)
     # ranges, the one-observation-per-(pose, point) rule and the index tables are the library's business (slam_ba_optimize_host_f64)
     try:
-        check(ctx.lib.slam_ba_optimize_host_f64(ctx.handle, K, L, O, T12.ctypes.data, X.ctypes.data, op.ctypes.data, ol.ctypes.data,
-                                                meas.ctypes.data, fixed.ctypes.data, fx, fy, cx, cy, float(huber_delta), int(iterations),
-                                                Tout.ctypes.data, Xout.ctypes.data, st.ctypes.data))
+        check(ctx.lib.slam_ba_optimize_host_f64(ctx.handle, K, L, O, addr(T12), addr(X), addr(op), addr(ol), addr(meas), addr(fixed),
+                                                fx, fy, cx, cy, float(huber_delta), int(iterations), addr(Tout), addr(Xout), addr(st)))
     except SlamHipError as exc:
         if exc.code == SLAM_ERR_INVALID:         # a bad argument, e.g. an index out of range or a pair observed twice
             raise ValueError(str(exc)) from None

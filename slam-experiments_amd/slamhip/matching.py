@@ -13,7 +13,7 @@ from typing import Optional, Sequence, Tuple
 
 import numpy as np
 
-from ._lib import DESC_BYTES, NO_MATCH_DIST, NO_MATCH_IDX, check
+from ._lib import DESC_BYTES, NO_MATCH_DIST, NO_MATCH_IDX, addr, check
 from .device import Context, DeviceBuffer, default_context
 
 NORM_HAMMING = 6           # cv2.NORM_HAMMING, the only norm the reference constructs (slam.py:24)
@@ -93,18 +93,8 @@ def knn_match_arrays(query, train, k: int = 2, ctx: Optional[Context] = None) ->
     idx = np.empty((n, 2), np.int32)
     dist = np.empty((n, 2), np.int32)
     if n:
-        check(ctx.lib.slam_bf_knn2_u256_host(ctx.handle, q.ctypes.data, n, t.ctypes.data if m else None, m,
-                                             idx.ctypes.data, dist.ctypes.data))
+        check(ctx.lib.slam_bf_knn2_u256_host(ctx.handle, addr(q), n, addr(t) if m else None, m, addr(idx), addr(dist)))
     return np.ascontiguousarray(idx[:, :k]), np.ascontiguousarray(dist[:, :k])
-
-
-def _addr(a: np.ndarray) -> int:
-    # the address of a C-contiguous array: 0.46 us through the buffer protocol against 1.3-1.4 us for `a.ctypes.data` or
-    # `a.__array_interface__` (a frame-sized match() needs two of them per call and is a 5 us kernel)
-    try:
-        return ctypes.addressof(ctypes.c_char.from_buffer(a))
-    except (TypeError, ValueError):              # a read-only or empty array has no writable buffer to borrow
-        return a.__array_interface__["data"][0]
 
 
 class _MatchOutputs:
@@ -123,7 +113,7 @@ class _MatchOutputs:
         if n > self.rows:
             self.rows = max(256, n + (n >> 2))
             self.qi, self.ti, self.dist = np.empty(self.rows, np.int32), np.empty(self.rows, np.int32), np.empty(self.rows, np.float32)
-            self.p_qi, self.p_ti, self.p_dist = _addr(self.qi), _addr(self.ti), _addr(self.dist)
+            self.p_qi, self.p_ti, self.p_dist = addr(self.qi), addr(self.ti), addr(self.dist)
 
 
 def _match_host(ctx: Context, q: np.ndarray, t: Optional[np.ndarray], d_train: Optional[DeviceBuffer], m: int,
@@ -132,8 +122,8 @@ def _match_host(ctx: Context, q: np.ndarray, t: Optional[np.ndarray], d_train: O
     n = q.shape[0]
     out = out or _MatchOutputs()
     out.reserve(n)
-    check(ctx.lib.slam_bf_match_host(ctx.handle, _addr(q) if n else None, n,
-                                     _addr(t) if t is not None and m else None,
+    check(ctx.lib.slam_bf_match_host(ctx.handle, addr(q) if n else None, n,
+                                     addr(t) if t is not None and m else None,
                                      d_train.ptr if d_train is not None and m else None, m,
                                      keep_query.ptr if keep_query is not None else None, mode, float(param),
                                      out.p_qi, out.p_ti, out.p_dist, out.p_cnt))

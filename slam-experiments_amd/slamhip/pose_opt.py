@@ -165,11 +165,11 @@ def optimize_pose_only_device(pose, points, meas, intrinsics, rounds: int = 4, i
     chi2 = np.zeros(O, np.float64)
     stats = np.zeros(2, np.int32)
     pin = np.ascontiguousarray(T0[:3, :4].reshape(12))
-    check(ctx.lib.slam_pose_optimize_host_f64(ctx.handle, pin.ctypes.data, points.ctypes.data if O else None,
-                                              meas.ctypes.data if O else None, O, fx, fy, cx, cy, int(rounds),
-                                              int(iterations), float(chi2_threshold), float(huber_delta),
-                                              out12.ctypes.data, inl.ctypes.data if O else None,
-                                              chi2.ctypes.data if O else None, stats.ctypes.data))
+    from ._lib import addr
+
+    check(ctx.lib.slam_pose_optimize_host_f64(ctx.handle, addr(pin), addr(points) if O else None, addr(meas) if O else None, O,
+                                              fx, fy, cx, cy, int(rounds), int(iterations), float(chi2_threshold), float(huber_delta),
+                                              addr(out12), addr(inl) if O else None, addr(chi2) if O else None, addr(stats)))
     T[:3, :4] = out12.reshape(3, 4)
     return PoseOptResult(pose=T, inliers=inl.astype(bool), chi2=chi2, n_inliers=int(stats[0]), iterations=int(stats[1]))
 
