@@ -1024,7 +1024,10 @@ static bf_plan make_plan_core(int num_cu, const int* k, int64_t N, int64_t M, st
     const int64_t resident = (int64_t)num_cu * SLAM_BF_RESIDENT;
     const int64_t W = resident / p.qblocks > 1 ? resident / p.qblocks : 1;   // (forced on a grid of many dispatch rounds: one)
     const bool can_queue = p.R == 1 && k[5] != -1 && !rows_on_host && qb_all <= p.qblocks && (M >= 16384 || k[8] == 1) && W >= 1;
-    const bool want_queue = k[8] == 1 || (k[8] == 0 && W >= 2 && W * p.qblocks * 10 >= resident * 8 && M >= 1024 * W);
+    // (fill: workers x query blocks must come to >= 96 % of the resident slots - the slots a queue plan leaves empty stay empty for
+    // the whole launch, where the one-block-per-chunk plans refill them: 120000 x 65536 at 91.6 % fill ran 5 % slower as a queue,
+    // 50000 x 20000 at 89 % 1.4 % slower, 20000 x 20000 at 97.7 % 7 % faster; profiles/r04_ab_queue.log "shapes")
+    const bool want_queue = k[8] == 1 || (k[8] == 0 && W >= 2 && W * p.qblocks * 100 >= resident * 96 && M >= 1024 * W);
     if (can_queue && want_queue) {
         int64_t c = k[7] ? k[7] : 256;
         const int64_t c_floor = (M / 3000 + 255) / 256 * 256;               // keeps the table within one ring slot

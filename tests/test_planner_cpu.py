@@ -82,8 +82,8 @@ def test_queue_plans_on_a_256_cu_device(plan):
         assert len(tbl) <= 4096, "the table fits one slot of the ring (no stream synchronisation when the shape changes)"
         assert p["merge"] == (1 if workers >= 12 else 0)              # many workers per query: they exchange by merging
         assert plan(n, m, merge=1)[0]["merge"] == 1 and plan(n, m, merge=-1)[0]["merge"] == 0
-    # not a queue: more query blocks than half the resident slots, few rows per worker, small train sets, batches, host rows
-    for (n, m), kw in (((200000, 65536), {}), ((1 << 20, 1 << 20), {}), ((100, 20000), {}), ((5000, 30000), {}), ((8192, 16000), {}), ((4096, 65536), {}),
+    # not a queue: more query blocks than half the resident slots, workers that would fill less than 96 % of the chip, few rows per worker, small train sets, batches, host rows
+    for (n, m), kw in (((200000, 65536), {}), ((1 << 20, 1 << 20), {}), ((100, 20000), {}), ((5000, 30000), {}), ((8192, 16000), {}), ((4096, 65536), {}), ((120000, 65536), {}), ((50000, 20000), {}),
                        ((8192, 65536), dict(qb_all=64)), ((8192, 65536), dict(rows_on_host=True)), ((8192, 65536), dict(queue=-1)),
                        ((8192, 65536), dict(feed=-1)), ((8192, 65536), dict(R=2))):
         assert plan(n, m, **kw)[0]["workers"] == 0, (n, m, kw)
