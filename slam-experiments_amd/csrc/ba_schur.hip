@@ -903,7 +903,7 @@ __device__ __forceinline__ double bg_quad_sum(double v) {
 #define BG_SYNC_OR_QUIT()                                   \
     do {                                                    \
         if (!bg_grid_sync(c, G, gen)) {                     \
-            if (blk == 0 && tid == 0) a.stats[5] = 1.0;     \
+            if (blk == 0 && tid == 0) a.stats[5] = (double)bg_load(&c->abort);   /* 1 = busy, 2 = bad index / table */ \
             return;                                         \
         }                                                   \
     } while (0)

@@ -506,7 +506,9 @@ def test_one_launch_ba_limits_are_reported(gpu_ctx):
 def test_one_launch_ba_ends_the_launch_on_an_index_outside_the_window(gpu_ctx):
     """slam_ba_optimize_f64 on device arrays (no host-side checks in front of it): an observation whose pose or point index
     lies outside the window is counted for slam_index_errors in the kernel's first phase and the launch ends there - status
-    1 in d_stats[5], the state untouched, nothing read out of bounds; the same window with the indices repaired runs."""
+    2 in d_stats[5] (1 is reserved for a launch that gave up at a grid barrier: device busy), the state untouched, nothing read
+    out of bounds; so are a free list that is not ascending below K and pose list heads that do not run from 0 to O (they
+    index LDS arrays: ADVICE r03); the same window with the indices repaired runs."""
     import ctypes
 
     rng = np.random.default_rng(5)
@@ -515,12 +517,14 @@ def test_one_launch_ba_ends_the_launch_on_an_index_outside_the_window(gpu_ctx):
     O = len(op)
     lib, ctx = gpu_ctx.lib, gpu_ctx
 
-    def run(op_, ol_):
+    def run(op_, ol_, free=None, spoil_ps_ptr=False):
         pt_obs = np.argsort(np.clip(ol_, 0, L - 1), kind="stable").astype(np.int32)
         ps_obs = np.argsort(np.clip(op_, 0, K - 1), kind="stable").astype(np.int32)
         pt_ptr = np.zeros(L + 1, np.int32); pt_ptr[1:] = np.cumsum(np.bincount(np.clip(ol_, 0, L - 1), minlength=L))
         ps_ptr = np.zeros(K + 1, np.int32); ps_ptr[1:] = np.cumsum(np.bincount(np.clip(op_, 0, K - 1), minlength=K))
-        free = np.arange(1, K, dtype=np.int32)
+        if spoil_ps_ptr:
+            ps_ptr[K] = O + 7                                   # the last pose's list would run past the observations
+        free = np.arange(1, K, dtype=np.int32) if free is None else np.asarray(free, np.int32)
         d = [ctx.upload(a) for a in (op_.astype(np.int32), ol_.astype(np.int32), meas, pt_ptr, pt_obs, ps_ptr, ps_obs, free)]
         state_T = np.concatenate([T[:, :3, :4].reshape(-1), np.zeros(K * 12)])
         state_X = np.concatenate([X.reshape(-1), np.zeros(L * 3)])
@@ -538,9 +542,13 @@ def test_one_launch_ba_ends_the_launch_on_an_index_outside_the_window(gpu_ctx):
     bad_op, bad_ol = op.copy(), ol.copy()
     bad_op[3] = K; bad_op[10] = -1; bad_ol[17] = L + 5
     st, Tout, Tin = run(bad_op, bad_ol)
-    assert st[5] == 1.0 and np.isnan(st[2])
+    assert st[5] == 2.0 and np.isnan(st[2])
     assert np.array_equal(Tout[:K * 12], Tin[:K * 12])
     assert lib.slam_index_errors(ctx.handle, ctypes.byref(cnt)) == 0 and cnt.value == 3
+    for kwargs, errors in ((dict(free=[2, 1, 3]), 1), (dict(free=[1, 2, K]), 1), (dict(spoil_ps_ptr=True), 1)):
+        st, Tout, Tin = run(op, ol, **kwargs)
+        assert st[5] == 2.0 and np.isnan(st[2]) and np.array_equal(Tout[:K * 12], Tin[:K * 12]), kwargs
+        assert lib.slam_index_errors(ctx.handle, ctypes.byref(cnt)) == 0 and cnt.value == errors, (kwargs, cnt.value)
     st, _, _ = run(op, ol)
     assert st[5] == 0.0 and st[2] >= 1 and st[1] < st[0]
     assert lib.slam_index_errors(ctx.handle, ctypes.byref(cnt)) == 0 and cnt.value == 0
