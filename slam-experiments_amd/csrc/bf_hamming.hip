@@ -69,6 +69,7 @@ typedef uint32_t u32;
 #define SLAM_KEY_NONE 0xFFFFFFFFu
 #define SLAM_ACC_BIAS 0x80000000u
 #define SLAM_BOUND_IDLE 0x7F7F7F7Fu  // bound[] between launches (one byte pattern: restored by memset as well)
+#define SLAM_L2_RESIDENT_ROWS 65536 // train sets up to this many rows (2 MiB) stay in every XCD's 4 MiB L2 once touched
 #define SLAM_CURSOR_STRIDE 32       // u32 words between the cursors of two query waves (one 128-byte line each)
 #define SLAM_BF_RESIDENT 6          // blocks of bf_top2_kernel<1, true, true> a CU holds at once (106 SGPRs: 6 waves per SIMD); queue plans
 
@@ -450,7 +451,11 @@ __device__ __forceinline__ void bf_top2_block(const uint4* __restrict__ q, int N
                 if (ci >= nchunks) break;
                 c0 = tbl[ci];
                 c1 = tbl[ci + 1];
-                if (fresh) warm = touch(c0);                     // later chunks: the XCD's L2 has seen the train set by then
+                // the chunk's first lines: on a wave's first chunk, and on every chunk of a train set that does not stay in an
+                // XCD's L2 (4 MiB; beyond that the front of the queues keeps moving into rows no L2 holds, and without the touch
+                // the scan's first scalar loads of every chunk wait for HBM: 131072 x 2^20, the per-rank problem of the loop-closure
+                // run, 34.5 ms without against 31.7 ms in round 3)
+                if (fresh || M > SLAM_L2_RESIDENT_ROWS) warm = touch(c0);
             }
             asm volatile("" ::"v"(warm));                        // the chunk's first lines are there: the scan starts right away
             int row = c0;
@@ -1027,7 +1032,11 @@ static bf_plan make_plan_core(int num_cu, const int* k, int64_t N, int64_t M, st
     // (fill: workers x query blocks must come to >= 96 % of the resident slots - the slots a queue plan leaves empty stay empty for
     // the whole launch, where the one-block-per-chunk plans refill them: 120000 x 65536 at 91.6 % fill ran 5 % slower as a queue,
     // 50000 x 20000 at 89 % 1.4 % slower, 20000 x 20000 at 97.7 % 7 % faster; profiles/r04_ab_queue.log "shapes")
-    const bool want_queue = k[8] == 1 || (k[8] == 0 && W >= 2 && W * p.qblocks * 100 >= resident * 96 && M >= 1024 * W);
+    // (and not two or three workers a query block over a train set far beyond the L2s: 131072 x 2^20 - the per-rank problem of the
+    // 8-GPU loop-closure run, three workers a query block - 32.25 ms as a queue against 31.80 ms one block per chunk, whose
+    // blocks of a dispatch round stream the same 4 MiB chunk together)
+    const bool want_queue = k[8] == 1 || (k[8] == 0 && W >= 2 && W * p.qblocks * 100 >= resident * 96 && M >= 1024 * W &&
+                                          (W >= 4 || M <= 131072));
     if (can_queue && want_queue) {
         int64_t c = k[7] ? k[7] : 256;
         const int64_t c_floor = (M / 3000 + 255) / 256 * 256;               // keeps the table within one ring slot
