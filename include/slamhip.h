@@ -159,13 +159,13 @@ SLAM_API int slam_bf_knn2_u256_host(slam_ctx* ctx, const uint8_t* h_query, int64
  *   [8] queue         1 = a queue plan: as many worker blocks per query block as are resident at once, whose waves draw
  *                     the chunks by ticket and keep their top-2 from chunk to chunk; -1 = one block per chunk (the plans
  *                     above).  Shipped: a queue plan for train sets of at least 16384 rows when every query block gets at
- *                     least two workers with at least 1024 rows apiece (four, for train sets beyond 131072 rows) and they fill at least 96 % of
+ *                     least two and at most 256 workers with at least 1024 rows apiece (four, for train sets beyond 131072 rows) and they fill at least 96 % of
  *                     the resident slots; then [7] forces the rows of a
  *                     uniform chunk, [4] > 0 the shortest chunk at the end of the queue, [4] = -1 no shrinking chunks
  *   [9] merge         how the workers of a queue plan exchange what they know: 1 = by merging their best two rows into the
  *                     per-query slot and reading its 2nd row back (the exact 2nd-best distance of everything folded in so
  *                     far), -1 = through a per-query bound (the minimum of the workers' own 2nd-best distances, as the
- *                     one-block-per-chunk plans do).  Shipped: merging from 12 workers per query block up */
+ *                     one-block-per-chunk plans do).  Shipped: merging from 12 to 96 workers per query block */
 #define SLAM_BF_KNOBS 10
 SLAM_API int slam_bf_set_tuning(slam_ctx* ctx, const int32_t* h_knobs, int count);
 /* The launch plan slam_bf_knn2_u256 would use for N x M on this context: h_plan int32 [10] =

@@ -1035,7 +1035,9 @@ static bf_plan make_plan_core(int num_cu, const int* k, int64_t N, int64_t M, st
     // (and not two or three workers a query block over a train set far beyond the L2s: 131072 x 2^20 - the per-rank problem of the
     // 8-GPU loop-closure run, three workers a query block - 32.25 ms as a queue against 31.80 ms one block per chunk, whose
     // blocks of a dispatch round stream the same 4 MiB chunk together)
-    const bool want_queue = k[8] == 1 || (k[8] == 0 && W >= 2 && W * p.qblocks * 100 >= resident * 96 && M >= 1024 * W &&
+    // (and at most 256 workers a query block: with 384 - 1000 queries - the one-block-per-chunk plan wins again, 129 against 138 us
+    // at 1000 x 400000; profiles/r04_ab_queue.log "many workers")
+    const bool want_queue = k[8] == 1 || (k[8] == 0 && W >= 2 && W <= 256 && W * p.qblocks * 100 >= resident * 96 && M >= 1024 * W &&
                                           (W >= 4 || M <= 131072));
     if (can_queue && want_queue) {
         int64_t c = k[7] ? k[7] : 256;
@@ -1061,8 +1063,10 @@ static bf_plan make_plan_core(int num_cu, const int* k, int64_t N, int64_t M, st
         p.cold = k[6] < 0 ? 0 : (k[6] ? k[6] : SLAM_COLD_ROWS);
         p.workers = (int)(W < p.S ? W : p.S);
         // the exact bound of a merge pays where many workers share a query (48 on the 1/8 shard: 148.5 -> 145.3 us; 24: 273 ->
-        // 266; six at 64k x 64k: 1015 -> 1022, where the minimum of six 2nd-best distances is nearly as good and costs less)
-        p.merge = k[9] == 1 || (k[9] == 0 && p.workers >= 12) ? 1 : 0;
+        // 266; six at 64k x 64k: 1015 -> 1022, where the minimum of six 2nd-best distances is nearly as good and costs less) -
+        // but not where VERY many do: from 128 workers up their atomics on one query's slot lines cost more than the tighter
+        // thresholds give (3000 x 200000, 128 workers: 182 us merging against 176 through bounds; 2048 x 262144, 192: 171 / 160)
+        p.merge = k[9] == 1 || (k[9] == 0 && p.workers >= 12 && p.workers <= 96) ? 1 : 0;
     }
     return p;
 }

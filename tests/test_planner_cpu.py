@@ -74,16 +74,17 @@ def test_queue_plans_on_a_256_cu_device(plan):
     """Round 4: train sets from 16384 rows up whose query blocks each get at least two resident workers with at least 1024
     rows apiece run as a QUEUE - workers x query blocks fill the chip once, the chunks of the table are drawn by ticket."""
     for (n, m), workers, chunk in (((8192, 65536), 48, 256), ((16384, 65536), 24, 256), ((32768, 65536), 12, 256),
-                                   ((65536, 65536), 6, 256), ((131072, 65536), 3, 256), ((32768, 1 << 18), 12, 256), ((20000, 20000), 19, 256)):
+                                   ((65536, 65536), 6, 256), ((131072, 65536), 3, 256), ((32768, 1 << 18), 12, 256), ((20000, 20000), 19, 256),
+                                   ((3000, 200000), 128, 256), ((2048, 1 << 18), 192, 256)):
         p, tbl = plan(n, m)
         assert p["workers"] == workers and p["chunk"] == chunk and p["resident"] == 6 and p["lead_rows"] == 0, (n, m, p)
         steps = np.diff(tbl)
         assert steps[0] == chunk and steps[-2] == 64 and p["tail_chunks"] > p["workers"]            # the queue ends on short chunks
         assert len(tbl) <= 4096, "the table fits one slot of the ring (no stream synchronisation when the shape changes)"
-        assert p["merge"] == (1 if workers >= 12 else 0)              # many workers per query: they exchange by merging
+        assert p["merge"] == (1 if 12 <= workers <= 96 else 0)        # many (not very many) workers per query: they exchange by merging
         assert plan(n, m, merge=1)[0]["merge"] == 1 and plan(n, m, merge=-1)[0]["merge"] == 0
     # not a queue: more query blocks than half the resident slots, workers that would fill less than 96 % of the chip, few rows per worker, small train sets, batches, host rows
-    for (n, m), kw in (((200000, 65536), {}), ((1 << 20, 1 << 20), {}), ((100, 20000), {}), ((5000, 30000), {}), ((8192, 16000), {}), ((4096, 65536), {}), ((120000, 65536), {}), ((50000, 20000), {}), ((131072, 1 << 20), {}),
+    for (n, m), kw in (((200000, 65536), {}), ((1 << 20, 1 << 20), {}), ((100, 20000), {}), ((5000, 30000), {}), ((8192, 16000), {}), ((4096, 65536), {}), ((120000, 65536), {}), ((50000, 20000), {}), ((131072, 1 << 20), {}), ((1000, 400000), {}),
                        ((8192, 65536), dict(qb_all=64)), ((8192, 65536), dict(rows_on_host=True)), ((8192, 65536), dict(queue=-1)),
                        ((8192, 65536), dict(feed=-1)), ((8192, 65536), dict(R=2))):
         assert plan(n, m, **kw)[0]["workers"] == 0, (n, m, kw)
