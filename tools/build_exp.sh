@@ -2,7 +2,8 @@
 # Builds the two experiment variants of libslamhip.so used by tools/trace_probe.py and tools/exp_probe.py into
 # tools/exp/ (development aid; nothing in the product or the tests loads them).  Both are the shipped sources with a
 # small patch applied to a temporary copy of bf_hamming.hip:
-#   libslamhip_trace.so      every block stamps wall_clock64() at start / after the prologue / after the scan / at the end
+#   libslamhip_trace.so      every block stamps wall_clock64() at start / after the prologue / after the scan / at the end,
+#                            and where it runs (HW_REG_HW_ID, HW_REG_XCC_ID), behind the stamps
 #   libslamhip_keepbound.so  the last arriver leaves the final 2nd-best distance in bound[] instead of restoring it
 #   libslamhip_count.so      counts, per launch, the 16-row groups and the single rows that take the update path
 #   libslamhip_cycles.so     wave 0 of every block stamps s_memtime (shader cycles) AND s_memrealtime (100 MHz) at block
@@ -21,7 +22,9 @@ python3 - "$SRC/bf_hamming.hip" "$TMP/bf_trace.hip" "$TMP/bf_keep.hip" "$TMP/bf_
 import sys
 src = open(sys.argv[1]).read()
 T = '    if (tid == 0 && g_trace) { g_trace[4*(by*(int)gridDim.x+bx)+%d] = wall_clock64(); }\n'
-s = src.replace('    const bool leader = !QUEUE && by < lead;\n', T % 0 + '    const bool leader = !QUEUE && by < lead;\n', 1)
+H = ('    if (g_trace) { unsigned hw_, xc_; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\\n\\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw_), "=s"(xc_));\n'
+     '        if (tid == 0) g_trace[4*(int)gridDim.x*(int)gridDim.y + by*(int)gridDim.x+bx] = ((unsigned long long)xc_ << 32) | hw_; }\n')   # where the block runs
+s = src.replace('    const bool leader = !QUEUE && by < lead;\n', T % 0 + H + '    const bool leader = !QUEUE && by < lead;\n', 1)
 s = s.replace('        int buf = 0;\n', '    ' + T % 1 + '        int buf = 0;\n', 1)
 s = s.replace('        bool fresh = true;', T % 1 + '        bool fresh = true;', 1)
 s = s.replace('    // ---- epilogue: merge,', T % 2 + '    // ---- epilogue: merge,', 1)
@@ -29,16 +32,16 @@ s = s.replace('    if (!s_last) return;\n', T % 3 + '    if (!s_last) return;\n'
 s = s.replace('typedef uint32_t u32;', 'typedef uint32_t u32;\n__device__ unsigned long long* g_trace = nullptr;\n'
               'extern "C" __attribute__((visibility("default"))) int slam_exp_set_trace(void* p) '
               '{ return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &p, sizeof(p)); }', 1)
-assert s.count('g_trace[') == 5, "trace hooks did not apply: the kernel source changed"
+assert s.count('g_trace[') == 6, "trace hooks did not apply: the kernel source changed"
 open(sys.argv[2], 'w').write(s)
 old = 'if (!merging) __hip_atomic_store(&st.bound[qi], SLAM_BOUND_IDLE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);'
-old2 = '__hip_atomic_store(&st.best[qi], ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);'
+old2 = 'const unsigned long long v = __hip_atomic_exchange(&st.best[qi], ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);'
 assert src.count(old) == 1 and src.count(old2) == 1, "keep-bound hooks did not apply: the kernel source changed"
 # bound form: the final 2nd-best distance stays in bound[]; merge form: the final pair stays in best[] (folding the same rows
 # again changes nothing) - either way the next search of the same inputs starts every block at its final threshold
 k = src.replace(old, 'if (!merging) __hip_atomic_store(&st.bound[qi], k2 == SLAM_KEY_NONE ? SLAM_BOUND_IDLE : '
                      '(k2 >> SLAM_KEY_IDX_BITS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);')
-k = k.replace(old2, 'if (!merging) ' + old2)
+k = k.replace(old2, old2 + ' if (merging) __hip_atomic_store(&st.best[qi], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);')
 open(sys.argv[3], 'w').write(k)
 g = '    if (__builtin_expect(__ballot((int)m >= 0) != 0ull, 0)) {\n'
 r = '            if (U > 1 && __ballot((int)mu >= 0) == 0ull) continue;\n'

@@ -33,7 +33,7 @@ blocks = plan[1] * (workers or plan[3])           # a queue plan launches `worke
 q = slamhip.DeviceDescriptors(ctx, np.random.default_rng(228).integers(0, 256, (n, 32), dtype=np.uint8))
 t = slamhip.DeviceDescriptors(ctx, np.random.default_rng(229).integers(0, 256, (m, 32), dtype=np.uint8))
 tab = slamhip.Top2Table(ctx, n)
-trace = ctx.malloc(blocks * 32)
+trace = ctx.malloc(blocks * 40)                     # four stamps a block, then one placement word a block
 f = lambda: lib.slam_bf_knn2_u256(h, q.buf.ptr, n, t.buf.ptr, m, 0, tab.idx.ptr, tab.dist.ptr)
 for _ in range(30):
     f()
@@ -42,7 +42,9 @@ assert lib.slam_exp_set_trace(trace.ptr) == 0
 ctx.timer_start()
 f()
 ms = ctx.timer_stop()
-tr = trace.download(np.uint64, (blocks, 4)).astype(np.int64)
+raw = trace.download(np.uint64, (blocks * 5,))
+tr = raw[:blocks * 4].reshape(blocks, 4).astype(np.int64)
+where = raw[blocks * 4:]
 TICK = 0.01   # wall_clock64 runs at 100 MHz: 10 ns per tick, in us
 t0 = tr[:, 0].min()
 start, pro, scan, end = ((tr[:, i] - t0) * TICK for i in range(4))
@@ -76,3 +78,21 @@ print("active blocks per 1/40 of the span:", " ".join(f"{a:.0f}" for a in act))
 full = np.array(act) >= 0.97 * min(slots, blocks)
 print(f"time below 97 % of full residency: head {bins[1:][full][0] - bins[1] if full.any() else span:.1f} us, "
       f"tail {span - bins[1:][full][-1] if full.any() else span:.1f} us")
+
+# Where the blocks ran: HW_REG_HW_ID (gfx9 layout: cu_id bits 11:8, sh_id 12, se_id 15:13) and HW_REG_XCC_ID (bits 3:0).
+hw, xcc = (where & 0xFFFFFFFF).astype(np.int64), (where >> 32).astype(np.int64) & 0xF
+cu = xcc * 4096 + ((hw >> 13) & 7) * 64 + ((hw >> 12) & 1) * 16 + ((hw >> 8) & 15)       # one number per physical CU
+ids, cnt = np.unique(cu, return_counts=True)
+print(f"placement: {len(ids)} CUs hold blocks; blocks per CU: " + ", ".join(f"{c} on {int((cnt == c).sum())}" for c in sorted(set(cnt))))
+print("  blocks per XCD: " + " ".join(str(int((xcc == x).sum())) for x in range(8)))
+for c in sorted(set(cnt)):
+    sel = np.isin(cu, ids[cnt == c])
+    print(f"  CUs with {c} blocks: wave 0 out of work at mean {scan[sel].mean():.1f} us (p5 {np.percentile(scan[sel], 5):.1f}, p95 {np.percentile(scan[sel], 95):.1f}), "
+          f"block end mean {end[sel].mean():.1f}, max {end[sel].max():.1f}")
+print("  by XCD, mean block end: " + " ".join(f"{end[xcc == x].mean():.1f}" for x in range(8) if (xcc == x).any()))
+if workers:
+    # a queue's workers by the load of the CU they sit on: does a query block whose workers landed on crowded CUs run dry later?
+    load = np.array([cnt[np.searchsorted(ids, c)] for c in cu])
+    per_q_load = np.array([load[bxs == b].mean() for b in range(qb)])
+    r = np.corrcoef(per_q_load, per_q)[0, 1] if per_q_load.std() > 0 else float("nan")
+    print(f"  mean CU load of a query block's workers: {per_q_load.min():.2f} .. {per_q_load.max():.2f}; correlation with the time its queue runs dry: {r:.2f}")
