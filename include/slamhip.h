@@ -194,7 +194,7 @@ SLAM_API int slam_bf_state_dirty(slam_ctx* ctx, int64_t* h_words);
  * that decodes a query block's result flags its queries as it writes them.
  *   mode 0: 1-NN of every query that has one (bf.match, feature_matchers.py:39,44)
  *   mode 2: Lowe ratio, kept iff dist0 < param * dist1 (strict; needs 2 neighbours) - BASELINE configs[1]
- * d_keep uint8 [N] (1 = kept); *h_count = rows kept, after one synchronisation (h_count NULL: asynchronous, no count).  Same
+ * d_keep uint8 [N] (1 = kept); *h_count = rows kept, once the search is done (h_count NULL: asynchronous, no count; with a count and <= 16384 queries the call waits by polling completion words in pinned memory, see slam_bf_match_host, otherwise it synchronises the stream).  Same
  * flags and count as slam_bf_knn2_u256 + slam_bf_match_filter; mode 1 (the min-distance filter) needs the global minimum
  * and stays there.  Train sets of more than 2^23 rows and empty ones run the two steps internally. */
 SLAM_API int slam_bf_knn2_select_u256(slam_ctx* ctx, const void* d_query, int64_t N, const void* d_train, int64_t M,
@@ -300,7 +300,11 @@ SLAM_API int slam_pose_optimize_batch_f64(slam_ctx* ctx, int64_t B, const double
  * as d_train.  mode/param as slam_bf_match_filter, plus mode 3 = crossCheck (cv2.BFMatcher(normType,
  * crossCheck=True).match; the reverse search runs in the same call, param unused).  Outputs (caller-allocated, N entries each): the kept
  * matches in ascending query order as query index, train index and distance (float32, integer-valued like
- * cv2's); *h_count = how many.  N == 0 or M == 0: no matches, not an error. */
+ * cv2's); *h_count = how many.  N == 0 or M == 0: no matches, not an error.
+ * Frame-sized calls (<= 4096 rows a side) return as soon as the call's last kernel has stored its completion word into
+ * pinned host memory behind its results - the host polls that word instead of synchronising the stream (about 4 us less
+ * per call); a call that is not complete after 2 ms of polling waits for the stream as before.  The outputs are complete
+ * when the function returns either way. */
 SLAM_API int slam_bf_match_host(slam_ctx* ctx, const uint8_t* h_query, int64_t N, const uint8_t* h_train,
                                 const void* d_train, int64_t M, void* d_query_keep, int mode, double param,
                                 int32_t* h_query_idx, int32_t* h_train_idx, float* h_distance, int64_t* h_count);

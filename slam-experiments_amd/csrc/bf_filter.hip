@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void filter_keep_kernel(const int2* __restrict
 #define FILTER_SMALL_MAX 16384
 __global__ __launch_bounds__(1024) void filter_small_kernel(const int2* __restrict__ idx, const int2* __restrict__ dist,
                                                             int N, int mode, double param, filter_scratch* s,
-                                                            uint8_t* __restrict__ keep) {
+                                                            uint8_t* __restrict__ keep, unsigned* done, unsigned epoch) {
     __shared__ int s_min[16];
     __shared__ unsigned int s_cnt[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -87,6 +87,7 @@ __global__ __launch_bounds__(1024) void filter_small_kernel(const int2* __restri
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) kept += __shfl_xor(kept, off, 64);
     if (lane == 0) s_cnt[wave] = kept;
+    if (done) __threadfence_system();      // the caller polls done[0] (slam_wait_done): the flags above are visible to the host first
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned long long c = 0;
@@ -94,6 +95,7 @@ __global__ __launch_bounds__(1024) void filter_small_kernel(const int2* __restri
         s->min_dist = min_dist;
         s->pad = 0;
         s->count = c;
+        if (done) __hip_atomic_store(done, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -102,13 +104,17 @@ static int filter_scratch_ptr(slam_ctx* ctx, filter_scratch** out) {
     return SLAM_OK;
 }
 
+// done / epoch: the one-workgroup form stores `epoch` into done[0] (pinned host memory) behind its flags, for a caller that
+// polls (slam_wait_done); *polled says whether it did (inputs beyond FILTER_SMALL_MAX take three kernels and do not).
 int slam_filter_launch(slam_ctx* ctx, const int32_t* d_idx, const int32_t* d_dist, int64_t N, int mode, double param,
-                       uint8_t* d_keep) {
+                       uint8_t* d_keep, unsigned* done, unsigned epoch, bool* polled) {
     filter_scratch* s = nullptr;
     if (int rc = filter_scratch_ptr(ctx, &s)) return rc;
+    if (polled) *polled = false;
     if (N <= FILTER_SMALL_MAX) {
         filter_small_kernel<<<1, 1024, 0, ctx->stream>>>((const int2*)d_idx, (const int2*)d_dist, (int)N, mode, param,
-                                                         s, d_keep);
+                                                         s, d_keep, done, epoch);
+        if (polled) *polled = done != nullptr;
     } else {
         const int blocks = (int)((N + 255) / 256 < 2048 ? (N + 255) / 256 : 2048);
         filter_init_kernel<<<1, 1, 0, ctx->stream>>>(s);

@@ -54,6 +54,7 @@
 //     tables, no merge kernel.
 //   * several independent searches can share one launch (bf_top2_batch_kernel).
 #include "internal.h"
+#include <chrono>
 #include "bf_scan_sgpr.h"
 #include <stdio.h>
 #include <vector>
@@ -300,7 +301,8 @@ struct bf_select {
     int* wave_kept;       // [ceil(N / 64)] rows kept in each group of 64 consecutive queries (device or pinned host memory)
     double param;         // mode 2: the ratio
     int mode;             // 0 = keep every query that has a neighbour, 2 = Lowe ratio: dist0 < param * dist1 (needs two neighbours)
-    int pad;
+    unsigned epoch;       // what the last arriver of query block x stores into done[x] once its results are visible to the host
+    unsigned* done;       // pinned host memory, or null: the caller synchronises the stream instead of polling (slam_wait_done)
 };
 
 // grid.x = query blocks of 256*R rows, grid.y = train chunks: block (x, y) scans rows [tbl[y], tbl[y+1]).  Every block
@@ -718,6 +720,15 @@ __device__ __forceinline__ void bf_top2_block(const uint4* __restrict__ q, int N
     if (tid == 0) __hip_atomic_store(&st.arrivals[bx], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (QUEUE && tid < 4)   // every worker of this query block has arrived, so nobody draws a ticket any more
         __hip_atomic_store(&st.cursor[(size_t)(4 * bx + tid) * SLAM_CURSOR_STRIDE], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (__builtin_expect(sel.done != nullptr, 0)) {   // (laid out behind the common path: tests/test_isa_handoff_cpu.py reads the text in order)
+        // A host thread polls done[bx] instead of synchronising the stream (frame-sized calls: 4 us less per call,
+        // tools/ubench/sync_vs_poll.hip).  Every thread makes its own result stores visible at system scope, the block meets,
+        // one lane releases the flag.  The state restores above need no such care: the next launch is ordered behind this
+        // one by the stream.
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(&sel.done[bx], sel.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 template <int R, bool SFEED, bool QUEUE>
@@ -753,23 +764,29 @@ struct bf_search {
     int N, lead, S, qblocks, train_base, first_block, cold, uni, M, sfeed;
 };
 struct bf_batch {
-    int count, pad;
+    int count;
+    unsigned epoch;              // polled completion (bf_select.done / .epoch): one word per query block of every search
+    unsigned* done;
     bf_search s[SLAM_BF_BATCH_MAX];
 };
 
 __global__ __launch_bounds__(256) void bf_top2_batch_kernel(const bf_batch b) {
     int i = 0;
     const int id = (int)blockIdx.x;
-    while (i + 1 < b.count && id >= b.s[i + 1].first_block) i++;
+    int done_base = 0;                              // the search's first completion word: one per query block, search after search
+    while (i + 1 < b.count && id >= b.s[i + 1].first_block) { done_base += b.s[i].qblocks; i++; }
     const bf_search& p = b.s[i];
     const int local = id - p.first_block;           // x fastest, as in the single search: consecutive blocks = consecutive query blocks
     const int bx = local % p.qblocks, by = local / p.qblocks;
+    bf_select sel{};
+    sel.epoch = b.epoch;
+    sel.done = b.done ? b.done + done_base : nullptr;
     if (p.sfeed)   // block-uniform: the search's train rows travel through SGPRs (short or long chunks in device memory)
         bf_top2_block<1, true, false>(p.q, p.N, p.t, p.tbl, p.lead, p.st, p.train_base, p.out_idx, p.out_dist, p.keep, bx, by, p.S, p.cold,
-                               p.uni, p.M, 0, 0, bf_select{});
+                               p.uni, p.M, 0, 0, sel);
     else
         bf_top2_block<1, false, false>(p.q, p.N, p.t, p.tbl, p.lead, p.st, p.train_base, p.out_idx, p.out_dist, p.keep, bx, by, p.S, p.cold,
-                                p.uni, p.M, 0, 0, bf_select{});
+                                p.uni, p.M, 0, 0, sel);
 }
 
 // merge G decoded tables by (dist, idx)
@@ -1263,9 +1280,50 @@ extern "C" int slam_bf_state_dirty(slam_ctx* ctx, int64_t* h_words) {
     return SLAM_OK;
 }
 
+// Waiting for a search by polling: the last arriver of every query block stores the call's epoch into a pinned word once its
+// results are visible to the host (bf_top2_block, sel.done).  Frame-sized calls return ~4 us earlier than through
+// hipStreamSynchronize (11.1 -> 6.7 us for an empty kernel, tools/ubench/sync_vs_poll.hip).  A search that is not done
+// after 2 ms of spinning - a long one, or a launch that failed - is waited for the ordinary way, which also surfaces errors;
+// and every 256th polled call synchronises anyway, so the runtime retires its completion signals at a bounded distance.
+// The context's pinned block: SLAM_BF_DONE_FLAGS completion words, then `extra` bytes (the fused selection's per-wave counts).
+int slam_done_block(slam_ctx* ctx, uint64_t extra) {
+    std::lock_guard<std::mutex> g(ctx->mu);
+    if (SLAM_BF_DONE_BYTES + extra > ctx->sel_host_bytes) {
+        SLAM_HIP(hipStreamSynchronize(ctx->stream));          // a queued search may still write the old block
+        if (ctx->sel_host) SLAM_HIP(hipHostFree(ctx->sel_host));
+        ctx->sel_host = nullptr;
+        ctx->sel_host_bytes = 0;
+        const uint64_t bytes = (SLAM_BF_DONE_BYTES + extra + 4095) / 4096 * 4096 * 2;
+        SLAM_HIP(hipHostMalloc(&ctx->sel_host, bytes, hipHostMallocDefault));
+        memset(ctx->sel_host, 0, bytes);
+        ctx->sel_host_bytes = bytes;
+    }
+    return SLAM_OK;
+}
+unsigned slam_done_epoch(slam_ctx* ctx) {
+    unsigned e = ++ctx->done_epoch;
+    if (e == 0) e = ++ctx->done_epoch;                        // (0 is what a fresh block holds)
+    return e;
+}
+int slam_wait_done(slam_ctx* ctx, const unsigned* flags, int count, unsigned epoch) {
+    const auto t0 = std::chrono::steady_clock::now();
+    bool done = false;
+    for (unsigned spins = 1; !done; spins++) {
+        int i = 0;
+        while (i < count && __atomic_load_n(&flags[i], __ATOMIC_ACQUIRE) == epoch) i++;
+        done = i == count;
+        if (done) break;
+        if ((spins & 255u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+        __builtin_ia32_pause();
+    }
+    if (!done || (++ctx->polled_calls & 255u) == 0) SLAM_HIP(hipStreamSynchronize(ctx->stream));
+    return SLAM_OK;
+}
+
 // one pass over at most 2^23 train rows
 static int bf_pass(slam_ctx* ctx, const void* d_query, int64_t N, const void* d_train, int64_t M,
-                   int64_t train_base, int32_t* d_idx, int32_t* d_dist, void* d_keep, const bf_select sel = bf_select{}) {
+                   int64_t train_base, int32_t* d_idx, int32_t* d_dist, void* d_keep, const bf_select sel = bf_select{},
+                   int* qblocks_out = nullptr) {
     std::vector<int> tbl;
     const bf_plan p = make_plan(ctx, N, M, &tbl, 0, bf_rows_on_host(ctx, d_train));
     bf_state st;
@@ -1289,6 +1347,7 @@ static int bf_pass(slam_ctx* ctx, const void* d_query, int64_t N, const void* d_
         if (fit >= 1 && fit < workers) workers = (int)fit;
     }
     const dim3 grid(p.qblocks, workers ? workers : p.S), block(256);
+    if (qblocks_out) *qblocks_out = p.qblocks;
     const int nchunks = workers ? p.S : 0;
     const uint4* q = (const uint4*)d_query;
     const uint4* t = (const uint4*)d_train;
@@ -1389,25 +1448,27 @@ int slam_bf_knn2_select(slam_ctx* ctx, const void* d_query, int64_t N, const voi
     SLAM_REQUIRE(train_base >= 0 && train_base + M <= 0x7FFFFFFFll, "train_base + M must fit int32");
     SLAM_HIP(hipSetDevice(ctx->device));
     const int64_t waves = (N + 63) / 64;                            // groups of 64 consecutive queries
-    {
-        std::lock_guard<std::mutex> g(ctx->mu);
-        if ((uint64_t)waves * 4 > ctx->sel_host_bytes) {
-            SLAM_HIP(hipStreamSynchronize(ctx->stream));          // a queued search may still write the old block
-            if (ctx->sel_host) SLAM_HIP(hipHostFree(ctx->sel_host));
-            ctx->sel_host = nullptr;
-            ctx->sel_host_bytes = 0;
-            const uint64_t bytes = ((uint64_t)waves * 4 + 4095) / 4096 * 4096 * 2;
-            SLAM_HIP(hipHostMalloc(&ctx->sel_host, bytes, hipHostMallocDefault));
-            ctx->sel_host_bytes = bytes;
-        }
-    }
+    if (int rc = slam_done_block(ctx, (uint64_t)waves * 4)) return rc;
+    // the pinned block: SLAM_BF_DONE_FLAGS completion words (one per query block of a search that is waited for by polling),
+    // then the per-wave counts
     bf_select sel;
-    sel.keep = d_sel_keep; sel.wave_kept = (int*)ctx->sel_host; sel.param = param; sel.mode = mode; sel.pad = 0;
-    if (int rc = bf_pass(ctx, d_query, N, d_train, M, train_base, d_idx, d_dist, d_query_keep, sel)) return rc;
+    sel.keep = d_sel_keep; sel.wave_kept = (int*)((char*)ctx->sel_host + SLAM_BF_DONE_BYTES); sel.param = param; sel.mode = mode;
+    sel.epoch = 0; sel.done = nullptr;
+    const bool poll = h_count && (N + 255) / 256 <= SLAM_BF_DONE_FLAGS;
+    if (poll) {
+        sel.done = (unsigned*)ctx->sel_host;
+        sel.epoch = slam_done_epoch(ctx);
+    }
+    int qblocks = 0;
+    if (int rc = bf_pass(ctx, d_query, N, d_train, M, train_base, d_idx, d_dist, d_query_keep, sel, &qblocks)) return rc;
     if (!h_count) return SLAM_OK;
-    SLAM_HIP(hipStreamSynchronize(ctx->stream));
+    if (poll) {
+        if (int rc = slam_wait_done(ctx, sel.done, qblocks, sel.epoch)) return rc;
+    } else {
+        SLAM_HIP(hipStreamSynchronize(ctx->stream));
+    }
     int64_t c = 0;
-    const volatile int* wk = (const volatile int*)ctx->sel_host;
+    const volatile int* wk = (const volatile int*)sel.wave_kept;
     for (int64_t w = 0; w < waves; w++) c += wk[w];
     *h_count = c;
     return SLAM_OK;
@@ -1421,11 +1482,15 @@ extern "C" int slam_bf_knn2_select_u256(slam_ctx* ctx, const void* d_query, int6
 
 // B independent searches in one launch (see bf_top2_batch_kernel).  h_keep: per search, where to leave a device copy of
 // its query rows (or null); may itself be null.
-int slam_bf_knn2_batch_keep(slam_ctx* ctx, int64_t B, const slam_bf_search* h_searches, void* const* h_keep) {
+int slam_bf_knn2_batch_keep(slam_ctx* ctx, int64_t B, const slam_bf_search* h_searches, void* const* h_keep, bool wait) {
     SLAM_REQUIRE(ctx, "slam_bf_knn2_batch_u256: null ctx");
     SLAM_REQUIRE(B >= 0 && B <= SLAM_BF_BATCH_MAX, "B=%lld searches, at most %d per call", (long long)B, SLAM_BF_BATCH_MAX);
     if (B == 0) return SLAM_OK;
     SLAM_REQUIRE(h_searches, "slam_bf_knn2_batch_u256: null search table");
+    // wait: the call returns when every search is done and its results are visible to the host - by polling the searches'
+    // completion words where that is possible (at most SLAM_BF_DONE_FLAGS query blocks, no search without train rows),
+    // otherwise by synchronising the stream
+    bool poll = wait;
     int64_t rows = 0, qb_all = 0;
     for (int64_t i = 0; i < B; i++) {
         const slam_bf_search& h = h_searches[i];
@@ -1442,6 +1507,8 @@ int slam_bf_knn2_batch_keep(slam_ctx* ctx, int64_t B, const slam_bf_search* h_se
     SLAM_HIP(hipSetDevice(ctx->device));
     bf_batch batch;
     memset(&batch, 0, sizeof(batch));
+    poll = poll && qb_all <= SLAM_BF_DONE_FLAGS;
+    int done_words = 0;
     std::vector<int> tables;
     std::vector<size_t> tbl_at;
     int64_t row0 = 0;
@@ -1453,6 +1520,7 @@ int slam_bf_knn2_batch_keep(slam_ctx* ctx, int64_t B, const slam_bf_search* h_se
         const slam_bf_search& h = h_searches[i];
         if (h.N == 0) continue;
         if (h.M == 0) {                                 // no train rows: every query reports "no neighbour"
+            poll = false;
             bf_fill_none_kernel<<<dim3((unsigned)((h.N + 255) / 256)), dim3(256), 0, ctx->stream>>>((int)h.N, (int2*)h.d_idx,
                                                                                                  (int2*)h.d_dist);
             SLAM_HIP(hipGetLastError());
@@ -1468,12 +1536,21 @@ int slam_bf_knn2_batch_keep(slam_ctx* ctx, int64_t B, const slam_bf_search* h_se
         d.st.best = st.best + row0; d.st.bound = st.bound + row0; d.st.arrivals = st.arrivals + row0 / 256; d.st.cursor = st.cursor + row0 / 64 * SLAM_CURSOR_STRIDE;
         d.N = (int)h.N; d.lead = p.lead; d.S = p.S; d.qblocks = p.qblocks; d.train_base = (int)h.train_base;
         d.first_block = blocks; d.cold = p.cold; d.uni = p.uni; d.M = (int)h.M; d.sfeed = p.sfeed;
+        done_words += p.qblocks;
         tbl_at.push_back(tables.size());
         if (!p.uni) tables.insert(tables.end(), tbl.begin(), tbl.end());
         blocks += p.qblocks * p.S;
         row0 += (h.N + 255) / 256 * 256;
     }
-    if (batch.count == 0) return SLAM_OK;
+    if (batch.count == 0) {
+        if (wait) SLAM_HIP(hipStreamSynchronize(ctx->stream));
+        return SLAM_OK;
+    }
+    if (poll) {
+        if (int rc = slam_done_block(ctx, 0)) return rc;
+        batch.done = (unsigned*)ctx->sel_host;
+        batch.epoch = slam_done_epoch(ctx);
+    }
     const int* d_tbl = nullptr;
     if (!tables.empty())
         if (int rc = bf_table_get(ctx, tables, &d_tbl)) return rc;
@@ -1487,11 +1564,13 @@ int slam_bf_knn2_batch_keep(slam_ctx* ctx, int64_t B, const slam_bf_search* h_se
         (void)slam_bf_reset_state(ctx);
         return slam_set_error(SLAM_ERR_HIP, "batched top-2 kernel launch failed: %s", hipGetErrorString(e));
     }
+    if (poll) return slam_wait_done(ctx, batch.done, done_words, batch.epoch);
+    if (wait) SLAM_HIP(hipStreamSynchronize(ctx->stream));
     return SLAM_OK;
 }
 
 extern "C" int slam_bf_knn2_batch_u256(slam_ctx* ctx, int64_t B, const slam_bf_search* h_searches) {
-    return slam_bf_knn2_batch_keep(ctx, B, h_searches, nullptr);
+    return slam_bf_knn2_batch_keep(ctx, B, h_searches, nullptr, false);
 }
 
 extern "C" int slam_bf_merge_top2(slam_ctx* ctx, const int32_t* d_idx_parts, const int32_t* d_dist_parts,

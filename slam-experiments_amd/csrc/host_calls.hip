@@ -30,7 +30,7 @@ extern "C" int slam_bf_knn2_u256_host(slam_ctx* ctx, const uint8_t* h_query, int
     SLAM_HIP(hipSetDevice(ctx->device));
     const uint64_t qbytes = (uint64_t)N * SLAM_DESC_BYTES, tbytes = (uint64_t)M * SLAM_DESC_BYTES;
     const uint64_t off_t = align_up(qbytes, 256), off_i = off_t + align_up(tbytes, 256);
-    const uint64_t off_d = off_i + (uint64_t)N * 8, total = align_up(off_d + (uint64_t)N * 8, 256);
+    const uint64_t off_d = off_i + (uint64_t)N * 8, off_k = off_d + (uint64_t)N * 8, total = align_up(off_k + (uint64_t)N, 256);
     void *dev = nullptr, *host = nullptr;
     if (int rc = slam_io_arena(ctx, total, total, &dev, &host)) return rc;
     uint8_t* hb = (uint8_t*)host;
@@ -39,15 +39,22 @@ extern "C" int slam_bf_knn2_u256_host(slam_ctx* ctx, const uint8_t* h_query, int
     if (tbytes) memcpy(hb + off_t, h_train, tbytes);
     ctx->io_h2d_bytes += qbytes + tbytes;
     ctx->io_d2h_bytes += (uint64_t)N * 16;
-    if (zero_copy(N, M)) {
-        // frame-sized: the kernels read the pinned block and write the result into it over PCIe themselves
+    if (zero_copy(N, M) && M > 0) {
+        // frame-sized: the kernels read the pinned block and write the result into it over PCIe themselves, and the call
+        // waits for the search's completion words instead of the stream (slam_bf_knn2_select with a count: ~4 us less; the
+        // has-a-neighbour flags it leaves behind the tables are a by-product)
+        int64_t with_neighbour = 0;
+        if (int rc = slam_bf_knn2_select(ctx, hb, N, hb + off_t, M, 0, (int32_t*)(hb + off_i), (int32_t*)(hb + off_d), nullptr, 0, 0.0,
+                                         hb + off_k, &with_neighbour)) return rc;
+    } else if (zero_copy(N, M)) {
         if (int rc = slam_bf_knn2_u256(ctx, hb, N, hb + off_t, M, 0, (int32_t*)(hb + off_i), (int32_t*)(hb + off_d))) return rc;
+        SLAM_HIP(hipStreamSynchronize(ctx->stream));
     } else {
         SLAM_HIP(hipMemcpyAsync(db, hb, off_t + tbytes, hipMemcpyHostToDevice, ctx->stream));
         if (int rc = slam_bf_knn2_u256(ctx, db, N, db + off_t, M, 0, (int32_t*)(db + off_i), (int32_t*)(db + off_d))) return rc;
         SLAM_HIP(hipMemcpyAsync(hb + off_i, db + off_i, (uint64_t)N * 16, hipMemcpyDeviceToHost, ctx->stream));
+        SLAM_HIP(hipStreamSynchronize(ctx->stream));
     }
-    SLAM_HIP(hipStreamSynchronize(ctx->stream));
     memcpy(h_idx, hb + off_i, (uint64_t)N * 8);
     memcpy(h_dist, hb + off_d, (uint64_t)N * 8);
     return SLAM_OK;
@@ -126,7 +133,7 @@ extern "C" int slam_bf_match_host(slam_ctx* ctx, const uint8_t* h_query, int64_t
             // to back cost two launch + drain latencies (200 features: 0.057 -> 0.04 ms per call)
             const slam_bf_search both[2] = {{dq, N, dt, M, 0, fwd_idx, fwd_dist}, {dt, M, dq, N, 0, rev_idx, rev_dist}};
             void* const keeps[2] = {keep_in_kernel, nullptr};
-            if (int rc = slam_bf_knn2_batch_keep(ctx, 2, both, keeps)) return rc;
+            if (int rc = slam_bf_knn2_batch_keep(ctx, 2, both, keeps, zc)) return rc;    // frame-sized: waits by polling
         } else {
             if (int rc = slam_bf_knn2_keep(ctx, dq, N, dt, M, 0, fwd_idx, fwd_dist, keep_in_kernel)) return rc;
             if (int rc = slam_bf_knn2_u256(ctx, dt, M, dq, N, 0, rev_idx, rev_dist)) return rc;
@@ -134,7 +141,7 @@ extern "C" int slam_bf_match_host(slam_ctx* ctx, const uint8_t* h_query, int64_t
         int64_t c = 0;
         if (zc) {
             ctx->io_d2h_bytes += (uint64_t)N * 8 + (uint64_t)M * 16;     // the four tables instead of the emitted pair
-            SLAM_HIP(hipStreamSynchronize(ctx->stream));
+            if (!(N <= SLAM_MAX_TRAIN_PER_PASS && M <= SLAM_MAX_TRAIN_PER_PASS)) SLAM_HIP(hipStreamSynchronize(ctx->stream));
             for (int64_t n = 0; n < N; n++) {
                 const int32_t t = fwd_idx[2 * n];
                 if (t < 0 || t >= M || rev_idx[2 * (int64_t)t] != (int32_t)n) continue;
@@ -167,15 +174,31 @@ extern "C" int slam_bf_match_host(slam_ctx* ctx, const uint8_t* h_query, int64_t
     // the Lowe ratio test (mode 2) needs none either and is made by the search's own decode (slam_bf_knn2_select);
     // the min-distance filter (mode 1, feature_matchers.py:41-43) needs the global minimum: its own kernel
     const bool select = mode != 0;
-    if (mode == 2) {
+    bool waited = false;
+    if (zc && mode != 1) {
+        // frame-sized (the reference's own call): the results land in the pinned block and the call waits for the search's
+        // completion words instead of the stream (bf_wait_done: ~4 us of a 22 us call); mode 0's flags say "has a neighbour"
+        int64_t kept = 0;
+        if (int rc = slam_bf_knn2_select(ctx, dq, N, dt, M, 0, d_idx, d_dist, keep_in_kernel, mode, param, io + off_k, &kept)) return rc;
+        waited = true;
+    } else if (mode == 2) {
         if (int rc = slam_bf_knn2_select(ctx, dq, N, dt, M, 0, d_idx, d_dist, keep_in_kernel, 2, param, io + off_k, nullptr)) return rc;
     } else {
         if (int rc = slam_bf_knn2_keep(ctx, dq, N, dt, M, 0, d_idx, d_dist, keep_in_kernel)) return rc;
-        if (select)
+        if (select && zc) {
+            // the min-distance filter's one-workgroup kernel is the call's last: it stores the completion word
+            if (int rc = slam_done_block(ctx, 0)) return rc;
+            unsigned* done = (unsigned*)ctx->sel_host;
+            const unsigned epoch = slam_done_epoch(ctx);
+            if (int rc = slam_filter_launch(ctx, d_idx, d_dist, N, mode, param, io + off_k, done, epoch, &waited)) return rc;
+            if (waited)
+                if (int rc = slam_wait_done(ctx, done, 1, epoch)) return rc;
+        } else if (select) {
             if (int rc = slam_filter_launch(ctx, d_idx, d_dist, N, mode, param, io + off_k)) return rc;
+        }
     }
     if (!zc) SLAM_HIP(hipMemcpyAsync(hb + off_i, db + off_i, (uint64_t)N * (select ? 17 : 16), hipMemcpyDeviceToHost, ctx->stream));
-    SLAM_HIP(hipStreamSynchronize(ctx->stream));
+    if (!waited) SLAM_HIP(hipStreamSynchronize(ctx->stream));
     // compact the kept rows (for modes 1 and 2 the selection itself was made on the device)
     const int32_t* ri = (const int32_t*)(hb + off_i);
     const int32_t* rd = (const int32_t*)(hb + off_d);

@@ -5,6 +5,7 @@
 #include <stdarg.h>
 #include <string.h>
 #include <unordered_map>
+#include <atomic>
 #include <mutex>
 #include "slamhip.h"
 
@@ -34,6 +35,7 @@ struct slam_ctx {
     void* scratch = nullptr;                        // 4 KiB device scratch (filter counters, reductions)
     void* sel_host = nullptr;                       // pinned host block the search's fused selection writes its per-wave counts to
     uint64_t sel_host_bytes = 0;
+    std::atomic<unsigned> done_epoch{0}, polled_calls{0};   // searches waited for by polling the block's completion words (bf_wait_done)
     void* io_dev = nullptr;                         // device arena of the host-buffer entry points (grow-only)
     uint64_t io_dev_bytes = 0;
     void* io_host = nullptr;                        // pinned host staging for the same (grow-only)
@@ -82,10 +84,17 @@ int slam_bf_knn2_select(slam_ctx* ctx, const void* d_query, int64_t N, const voi
                         int32_t* d_idx, int32_t* d_dist, void* d_query_keep, int mode, double param, uint8_t* d_sel_keep,
                         int64_t* h_count);
 // slam_bf_knn2_batch_u256 with optional per-search copies of the query rows (h_keep[i] or null; h_keep may be null)
-int slam_bf_knn2_batch_keep(slam_ctx* ctx, int64_t B, const slam_bf_search* h_searches, void* const* h_keep);
+int slam_bf_knn2_batch_keep(slam_ctx* ctx, int64_t B, const slam_bf_search* h_searches, void* const* h_keep, bool wait = false);
+// Completion by polling (bf_hamming.hip, slam_wait_done): the context's pinned block starts with SLAM_BF_DONE_FLAGS words that
+// the last kernel of a frame-sized call stores its epoch into once the results are visible to the host.
+#define SLAM_BF_DONE_FLAGS 64
+#define SLAM_BF_DONE_BYTES (SLAM_BF_DONE_FLAGS * 4)
+int slam_done_block(slam_ctx* ctx, uint64_t extra);
+unsigned slam_done_epoch(slam_ctx* ctx);
+int slam_wait_done(slam_ctx* ctx, const unsigned* flags, int count, unsigned epoch);
 // the filter kernels of slam_bf_match_filter without the read-back (asynchronous on the ctx stream)
 int slam_filter_launch(slam_ctx* ctx, const int32_t* d_idx, const int32_t* d_dist, int64_t N, int mode, double param,
-                       uint8_t* d_keep);
+                       uint8_t* d_keep, unsigned* done = nullptr, unsigned epoch = 0, bool* polled = nullptr);
 // the crossCheck kernels of slam_bf_cross_check without the read-back (asynchronous on the ctx stream)
 int slam_cross_launch(slam_ctx* ctx, const int32_t* d_fwd_idx, const int32_t* d_fwd_dist, int64_t N,
                       const int32_t* d_rev_idx, int64_t M, int32_t* d_out_idx, int32_t* d_out_dist);

@@ -77,7 +77,12 @@ def test_ticket_sits_behind_wait_and_barrier_and_the_last_arriver_reads_with_ato
     for name, ins in kernels.items():
         swaps = [k for k, i in enumerate(ins) if i.startswith("global_atomic_swap_x2")]
         assert swaps, f"{name}: the last arriver no longer takes the result slots with an atomic exchange"
-        assert not [i for i in ins if i.startswith("buffer_wbl2")], f"{name}: a release fence is back: say so in bf_hamming.hip"
+        # No release fence in the hand-off: round 3's was the agent-scope write-back (buffer_wbl2 sc1).  The only write-backs a
+        # kernel may hold are SYSTEM-scope ones (sc0 sc1): the polled completion (sel.done) - every thread of the last arriver
+        # makes its result stores visible to the host, one lane releases the completion word - which sits behind the decode
+        # (the compiler lays that block out wherever it likes, so the text order says nothing; the scope does).
+        wb = [i for i in ins if i.startswith("buffer_wbl2")]
+        assert all(i.split() == ["buffer_wbl2", "sc0", "sc1"] for i in wb), f"{name}: an agent-scope release fence is back: {sorted(set(wb))}"
         tickets = set()
         for at in swaps:
             assert " sc0" in ins[at], f"{name}: the exchange must return the slot"

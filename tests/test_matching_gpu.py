@@ -524,3 +524,43 @@ def test_selection_fused_into_the_search_equals_the_two_step_way(gpu_ctx, n, m):
     finally:
         for o in (tab, dq, e, keep):
             o.free()
+
+
+@pytest.mark.parametrize("n,m", [(16384, 600000), (16385, 3000), (200, 200)])
+def test_polled_completion_long_searches_and_its_limits(gpu_ctx, n, m):
+    """A search with a count is waited for by polling the completion words its last arrivers store into pinned memory
+    (slam_wait_done) when it has at most 64 query blocks.  16384 x 600000 has exactly 64 and runs longer than the 2 ms the
+    poll spins for (it falls back to the stream); 16385 rows are 65 query blocks (never polled); 200 x 200 three hundred times
+    in a row crosses the every-256th-call synchronisation.  Same count and flags as the two-step way, sampled rows against the
+    oracle, the merge state idle."""
+    import ctypes
+
+    import slamhip
+    from oracle import oracle
+
+    ctx = gpu_ctx
+    rng = np.random.default_rng(n * 7 + m)
+    q = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    t = rng.integers(0, 256, (m, 32), dtype=np.uint8)
+    k = min(n, m, 100)
+    t[rng.choice(m, k, replace=False)] = q[rng.choice(n, k, replace=False)]
+    dq, dt = slamhip.DeviceDescriptors(ctx, q), slamhip.DeviceDescriptors(ctx, t)
+    tab, keep, keep2 = slamhip.Top2Table(ctx, n), ctx.malloc(n + 64), ctx.malloc(n + 64)
+    try:
+        for rep in range(300 if n == 200 else 2):
+            got = slamhip.knn2_select_device(ctx, dq.buf, n, dt.buf, m, tab.idx, tab.dist, keep, 2, 0.8)
+            if rep % 100 == 0 or n != 200:
+                idx, dist = tab.download()
+                flags = keep.download(np.uint8, (n,))
+                cnt, mind = ctypes.c_int64(0), ctypes.c_int32(0)
+                assert ctx.lib.slam_bf_match_filter(ctx.handle, tab.idx.ptr, tab.dist.ptr, n, 2, 0.8, keep2.ptr, ctypes.byref(cnt),
+                                                    ctypes.byref(mind)) == 0
+                assert cnt.value == got == int(flags.sum()) and np.array_equal(keep2.download(np.uint8, (n,)), flags)
+                sel = rng.choice(n, min(n, 128), replace=False)
+                ridx, rdist = oracle.bf_knn_c(q[sel], t, 2, threads=8)
+                assert np.array_equal(idx[sel], ridx) and np.array_equal(dist[sel], rdist)
+                assert got >= 1
+        assert ctx.state_dirty() == 0
+    finally:
+        for o in (tab, dq, dt, keep, keep2):
+            o.free()
