@@ -313,7 +313,8 @@ SLAM_API int slam_bf_match_host(slam_ctx* ctx, const uint8_t* h_query, int64_t N
  * (h2d), results copied or written in place (d2h).  Rows passed as device pointers (d_train) count nothing. */
 SLAM_API int slam_io_counters(slam_ctx* ctx, uint64_t* h2d_bytes, uint64_t* d2h_bytes);
 /* slam_pose_optimize_f64 on host buffers (Frontend._correct_current_pose, frontend.py:298-393): h_pose_in [12],
- * h_points [O,3], h_meas [O,2] -> h_pose_out [12], h_inlier uint8 [O], h_chi2 [O], h_stats int32 [2]. */
+ * h_points [O,3], h_meas [O,2] -> h_pose_out [12], h_inlier uint8 [O], h_chi2 [O], h_stats int32 [2].  Up to 512 edges the
+ * kernel reads and writes the pinned staging block itself and the call waits for its completion word (see slam_bf_match_host). */
 SLAM_API int slam_pose_optimize_host_f64(slam_ctx* ctx, const double* h_pose_in, const double* h_points,
                                          const double* h_meas, int64_t O, double fx, double fy, double cx,
                                          double cy, int rounds, int iterations, double chi2_threshold,

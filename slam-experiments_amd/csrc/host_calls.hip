@@ -242,14 +242,29 @@ extern "C" int slam_pose_optimize_host_f64(slam_ctx* ctx, const double* h_pose_i
     }
     ctx->io_h2d_bytes += off_m + 16 * o;
     ctx->io_d2h_bytes += out_inl + o - out_pose;
-    SLAM_HIP(hipMemcpyAsync(db, hb, off_m + 16 * o, hipMemcpyHostToDevice, ctx->stream));
-    if (int rc = slam_pose_optimize_f64(ctx, (const double*)db, (const double*)(db + off_p), (const double*)(db + off_m),
-                                        O, fx, fy, cx, cy, rounds, iterations, chi2_threshold, huber_delta,
-                                        (double*)(db + out_pose), db + out_inl, (double*)(db + out_chi2),
-                                        (int32_t*)(db + out_stats)))
-        return rc;
-    SLAM_HIP(hipMemcpyAsync(hb + out_pose, db + out_pose, out_inl + o - out_pose, hipMemcpyDeviceToHost, ctx->stream));
-    SLAM_HIP(hipStreamSynchronize(ctx->stream));
+    if (O <= SLAM_POSE_STAGE) {
+        // A frame's problem (<= 200 edges, slam.py:23) is staged into LDS by the kernel's first pass and its results are written
+        // once at the end: the kernel reads the pinned block and writes into it directly (no copy commands), and the call waits
+        // for the kernel's completion word instead of the stream (slam_wait_done).
+        if (int rc = slam_done_block(ctx, 0)) return rc;
+        unsigned* done = (unsigned*)ctx->sel_host;
+        const unsigned epoch = slam_done_epoch(ctx);
+        if (int rc = slam_pose_optimize_polled(ctx, (const double*)hb, (const double*)(hb + off_p), (const double*)(hb + off_m),
+                                               O, fx, fy, cx, cy, rounds, iterations, chi2_threshold, huber_delta,
+                                               (double*)(hb + out_pose), hb + out_inl, (double*)(hb + out_chi2),
+                                               (int32_t*)(hb + out_stats), done, epoch))
+            return rc;
+        if (int rc = slam_wait_done(ctx, done, 1, epoch)) return rc;
+    } else {
+        SLAM_HIP(hipMemcpyAsync(db, hb, off_m + 16 * o, hipMemcpyHostToDevice, ctx->stream));
+        if (int rc = slam_pose_optimize_f64(ctx, (const double*)db, (const double*)(db + off_p), (const double*)(db + off_m),
+                                            O, fx, fy, cx, cy, rounds, iterations, chi2_threshold, huber_delta,
+                                            (double*)(db + out_pose), db + out_inl, (double*)(db + out_chi2),
+                                            (int32_t*)(db + out_stats)))
+            return rc;
+        SLAM_HIP(hipMemcpyAsync(hb + out_pose, db + out_pose, out_inl + o - out_pose, hipMemcpyDeviceToHost, ctx->stream));
+        SLAM_HIP(hipStreamSynchronize(ctx->stream));
+    }
     memcpy(h_pose_out, hb + out_pose, 96);
     memcpy(h_stats, hb + out_stats, 8);
     if (O) {

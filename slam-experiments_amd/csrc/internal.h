@@ -92,6 +92,11 @@ int slam_bf_knn2_batch_keep(slam_ctx* ctx, int64_t B, const slam_bf_search* h_se
 int slam_done_block(slam_ctx* ctx, uint64_t extra);
 unsigned slam_done_epoch(slam_ctx* ctx);
 int slam_wait_done(slam_ctx* ctx, const unsigned* flags, int count, unsigned epoch);
+#define SLAM_POSE_STAGE 512      // edges the pose refinement keeps in LDS (pose_opt.hip PO_STAGE): up to here a host call is zero-copy
+int slam_pose_optimize_polled(slam_ctx* ctx, const double* d_pose_in, const double* d_points, const double* d_meas, int64_t O,
+                              double fx, double fy, double cx, double cy, int rounds, int iterations, double chi2_threshold,
+                              double huber_delta, double* d_pose_out, uint8_t* d_inlier, double* d_chi2, int32_t* d_stats,
+                              unsigned* done, unsigned epoch);
 // the filter kernels of slam_bf_match_filter without the read-back (asynchronous on the ctx stream)
 int slam_filter_launch(slam_ctx* ctx, const int32_t* d_idx, const int32_t* d_dist, int64_t N, int mode, double param,
                        uint8_t* d_keep, unsigned* done = nullptr, unsigned epoch = 0, bool* polled = nullptr);

@@ -36,7 +36,8 @@
 #define PO_TERMS 28   // 21 (upper H) + 6 (b) + 1 (robust chi2 of the active edges)
 #define PO_RED_STRIDE (PO_THREADS / 2 + 8)   // doubles per term in the reduction buffer: padded, so the 16-value reads of
                                              // thread (term, segment) fall on different LDS banks for different terms
-#define PO_STAGE 512  // observations kept in LDS (3 + 2 + 1 doubles and a flag each: 24.5 KiB)
+static_assert(SLAM_POSE_STAGE == 512, "host_calls.hip decides by it");
+#define PO_STAGE SLAM_POSE_STAGE  // observations kept in LDS (3 + 2 + 1 doubles and a flag each: 24.5 KiB)
 
 struct po_cam { double fx, fy, cx, cy; };
 
@@ -392,7 +393,8 @@ __global__ __launch_bounds__(PO_THREADS) void pose_opt_kernel(const double* __re
                                                               po_params prm, double* __restrict__ pose_out,
                                                               uint8_t* __restrict__ g_active,
                                                               double* __restrict__ g_chi2, int* __restrict__ stats,
-                                                              unsigned int* __restrict__ index_errors) {
+                                                              unsigned int* __restrict__ index_errors,
+                                                              unsigned* __restrict__ done, unsigned epoch) {
     if (offsets) {
         // O is the length of the concatenated arrays here.  A table that is not ascending or leaves [0, O] is the
         // caller's bug; it is reported (slam_index_errors) and the frame shrinks to what lies inside, never a wild access.
@@ -433,12 +435,28 @@ __global__ __launch_bounds__(PO_THREADS) void pose_opt_kernel(const double* __re
         stats[0] = prm.rounds > 0 ? nactive : O;   // inlier count: what _correct_current_pose returns (frontend.py:393)
         stats[1] = accepted;                        // accepted LM steps over all rounds
     }
+    if (done) {
+        // the host call polls this word instead of synchronising the stream (host_calls.hip; slam_wait_done): every thread's
+        // result stores - they went straight into pinned host memory - are visible to the host before one lane releases it
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(done, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 extern "C" int slam_pose_optimize_f64(slam_ctx* ctx, const double* d_pose_in, const double* d_points,
                                       const double* d_meas, int64_t O, double fx, double fy, double cx, double cy,
                                       int rounds, int iterations, double chi2_threshold, double huber_delta,
                                       double* d_pose_out, uint8_t* d_inlier, double* d_chi2, int32_t* d_stats) {
+    return slam_pose_optimize_polled(ctx, d_pose_in, d_points, d_meas, O, fx, fy, cx, cy, rounds, iterations, chi2_threshold,
+                                     huber_delta, d_pose_out, d_inlier, d_chi2, d_stats, nullptr, 0);
+}
+
+// slam_pose_optimize_f64 whose kernel stores `epoch` into *done (pinned host memory) behind its results, or done == nullptr
+int slam_pose_optimize_polled(slam_ctx* ctx, const double* d_pose_in, const double* d_points, const double* d_meas, int64_t O,
+                              double fx, double fy, double cx, double cy, int rounds, int iterations, double chi2_threshold,
+                              double huber_delta, double* d_pose_out, uint8_t* d_inlier, double* d_chi2, int32_t* d_stats,
+                              unsigned* done, unsigned epoch) {
     SLAM_REQUIRE(ctx, "slam_pose_optimize_f64: null ctx");
     SLAM_REQUIRE(O >= 0 && O <= (1 << 24), "O=%lld out of range [0, 2^24]", (long long)O);
     SLAM_REQUIRE(rounds >= 0 && iterations >= 0 && rounds <= 64 && iterations <= 1000, "bad rounds / iterations");
@@ -449,7 +467,7 @@ extern "C" int slam_pose_optimize_f64(slam_ctx* ctx, const double* d_pose_in, co
     const po_cam cam = {fx, fy, cx, cy};
     const po_params prm = {rounds, iterations, chi2_threshold, huber_delta};
     pose_opt_kernel<<<1, PO_THREADS, 0, ctx->stream>>>(d_pose_in, d_points, (const double2*)d_meas, (int)O, nullptr, cam, prm,
-                                                       d_pose_out, d_inlier, d_chi2, d_stats, slam_index_error_counter(ctx));
+                                                       d_pose_out, d_inlier, d_chi2, d_stats, slam_index_error_counter(ctx), done, epoch);
     SLAM_HIP(hipGetLastError());
     return SLAM_OK;
 }
@@ -470,7 +488,7 @@ extern "C" int slam_pose_optimize_batch_f64(slam_ctx* ctx, int64_t B, const doub
     const po_cam cam = {fx, fy, cx, cy};
     const po_params prm = {rounds, iterations, chi2_threshold, huber_delta};
     pose_opt_kernel<<<(unsigned)B, PO_THREADS, 0, ctx->stream>>>(d_pose_in, d_points, (const double2*)d_meas, (int)O_total, d_offsets, cam, prm,
-                                                                 d_pose_out, d_inlier, d_chi2, d_stats, slam_index_error_counter(ctx));
+                                                                 d_pose_out, d_inlier, d_chi2, d_stats, slam_index_error_counter(ctx), nullptr, 0u);
     SLAM_HIP(hipGetLastError());
     return SLAM_OK;
 }
