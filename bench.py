@@ -250,7 +250,7 @@ def next_rows_leg(ctx, cpu: bool = True) -> dict:
     call = lambda: be.optimize_pose(T0, X, pix, fx, fy, cx, cy, on_device=True)
     r = call()
     out["pose_lm"] = {"edges": E, "ms_per_call": best(call, 20) * 1e3, "accepted_steps": int(r.iterations), "inliers": int(r.n_inliers),
-                      "call": "Backend.optimize_pose (slam_pose_optimize_host_f64: one upload, one launch, one download)"}
+                      "call": "Backend.optimize_pose (slam_pose_optimize_host_f64: the kernel reads and writes the pinned block, one launch, completion polled)"}
     if cpu:
         from oracle import oracle
         p12 = np.ascontiguousarray(T0[:3, :4].reshape(12))
