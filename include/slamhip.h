@@ -292,7 +292,7 @@ SLAM_API int slam_pose_optimize_batch_f64(slam_ctx* ctx, int64_t B, const double
                                           double chi2_threshold, double huber_delta, double* d_pose_out,
                                           uint8_t* d_inlier, double* d_chi2, int32_t* d_stats);
 
-/* ---- per-frame calls on caller-owned host buffers: one upload, one download, one synchronisation ---- */
+/* ---- per-frame calls on caller-owned host buffers: one upload, one download, one wait (frame-sized: zero-copy, polled) ---- */
 /* BruteForceFeatureMatcher.match (feature_matchers.py:36-44; cv2.BFMatcher.match + the min-distance filter) in
  * one call.  Query rows h_query [N,32]; train rows either h_train [M,32] (host) or d_train (device, e.g. the
  * previous frame kept by an earlier call) - exactly one of them when M > 0.  If d_query_keep is non-null the

@@ -3,7 +3,8 @@
 // At the reference's own sizes (<= 200 features per frame, slam.py:23) the kernels take tens of
 // microseconds and what a call costs is the number of PCIe round trips and synchronisations around them.
 // Each function here packs its inputs into one pinned staging block, does ONE host-to-device copy,
-// launches everything on the context stream, does ONE device-to-host copy and synchronises once.
+// launches everything on the context stream, does ONE device-to-host copy and synchronises once - or, frame-sized, does no
+// copy at all (the kernels read and write the pinned block) and waits for the last kernel's completion word (slam_wait_done).
 // The staging block belongs to the context, so these calls serialise per context (ctypes drops the GIL:
 // the reference's tracking thread and a backend thread may both be in here).
 //   slam_bf_knn2_u256_host       cv2.BFMatcher.knnMatch(k=2) (the search behind feature_matchers.py:39)

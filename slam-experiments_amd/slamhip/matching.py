@@ -118,7 +118,7 @@ class _MatchOutputs:
 
 def _match_host(ctx: Context, q: np.ndarray, t: Optional[np.ndarray], d_train: Optional[DeviceBuffer], m: int,
                 keep_query: Optional[DeviceBuffer], mode: int, param: float, out: Optional[_MatchOutputs] = None):
-    """One ``slam_bf_match_host`` call: upload, top-2 search, selection, download, one synchronisation."""
+    """One ``slam_bf_match_host`` call: upload, top-2 search, selection, download, one wait (frame-sized: zero-copy, completion polled)."""
     n = q.shape[0]
     out = out or _MatchOutputs()
     out.reserve(n)
@@ -225,7 +225,7 @@ def knn2_select_device(ctx: Context, d_query: DeviceBuffer, n: int, d_train: Dev
     """Top-2 search + selection in ONE launch on device-resident rows (``slam_bf_knn2_select_u256``): ``mode`` 0 keeps every
     query that has a neighbour, 2 is the Lowe ratio test ``dist0 < param * dist1`` (BASELINE configs[1]: knn = 2 + ratio).
     The tables go to ``d_idx`` / ``d_dist`` as ``knn2_device`` leaves them, one flag per query to ``d_keep`` (uint8 [n]);
-    returns how many were kept (one synchronisation)."""
+    returns how many were kept (one wait: the completion words up to 16384 queries, else the stream)."""
     cnt = ctypes.c_int64(0)
     check(ctx.lib.slam_bf_knn2_select_u256(ctx.handle, d_query.ptr if n else None, n, d_train.ptr if m else None, m, train_base,
                                            d_idx.ptr, d_dist.ptr, mode, float(param), d_keep.ptr, ctypes.byref(cnt)))
