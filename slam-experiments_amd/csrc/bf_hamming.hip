@@ -1057,7 +1057,10 @@ static bf_plan make_plan_core(int num_cu, const int* k, int64_t N, int64_t M, st
     const bool want_queue = k[8] == 1 || (k[8] == 0 && W >= 2 && W <= 256 && W * p.qblocks * 100 >= resident * 96 && M >= 1024 * W &&
                                           (W >= 4 || M <= 131072));
     if (can_queue && want_queue) {
-        int64_t c = k[7] ? k[7] : 256;
+        // 256-row chunks; 1024 where a worker has 16384 rows or more to itself (fewer tickets and exchanges: 131072 x 65536 2078 ->
+        // 2063 us, 20000 x 400000 1977 -> 1965, 16384 x 524288 2059 -> 2049; at 64k x 64k, 10923 rows a worker, 256 is still the
+        // better one: 1020.8 against 1027.3; profiles/r04_ab_queue.log "chunk length")
+        int64_t c = k[7] ? k[7] : (M / W >= 16384 ? 1024 : 256);
         const int64_t c_floor = (M / 3000 + 255) / 256 * 256;               // keeps the table within one ring slot
         if (c < c_floor) c = c_floor;
         const bool guided = k[4] >= 0;
@@ -1310,6 +1313,8 @@ int slam_wait_done(slam_ctx* ctx, const unsigned* flags, int count, unsigned epo
     bool done = false;
     for (unsigned spins = 1; !done; spins++) {
         int i = 0;
+        // (== and not "this epoch or a later one": two threads on one context may draw their epochs and launch in different
+        // orders; a word overwritten by the other thread's call is then simply never seen, and the wait falls back to the stream)
         while (i < count && __atomic_load_n(&flags[i], __ATOMIC_ACQUIRE) == epoch) i++;
         done = i == count;
         if (done) break;
@@ -1423,7 +1428,8 @@ int slam_bf_knn2_keep(slam_ctx* ctx, const void* d_query, int64_t N, const void*
 
 // slam_bf_knn2_u256 + a selection that needs no reduction over the queries, in ONE launch (see bf_select).  d_sel_keep u8 [N];
 // the rows kept by each wave land in pinned host memory owned by the context (written by the kernel itself: no copy command),
-// and *h_count is their sum after ONE synchronisation.  h_count may be null: then nothing is waited for (asynchronous, the
+// and *h_count is their sum once the search is done (polled completion words up to SLAM_BF_DONE_FLAGS query blocks, else one
+// synchronisation).  h_count may be null: then nothing is waited for (asynchronous, the
 // flags are in d_sel_keep when the stream gets there).  Train sets that need several passes and empty ones take the two-step
 // way (search, then slam_filter_launch).
 int slam_bf_knn2_select(slam_ctx* ctx, const void* d_query, int64_t N, const void* d_train, int64_t M, int64_t train_base,

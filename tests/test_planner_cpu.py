@@ -74,8 +74,8 @@ def test_queue_plans_on_a_256_cu_device(plan):
     """Round 4: train sets from 16384 rows up whose query blocks each get at least two resident workers with at least 1024
     rows apiece run as a QUEUE - workers x query blocks fill the chip once, the chunks of the table are drawn by ticket."""
     for (n, m), workers, chunk in (((8192, 65536), 48, 256), ((16384, 65536), 24, 256), ((32768, 65536), 12, 256),
-                                   ((65536, 65536), 6, 256), ((131072, 65536), 3, 256), ((32768, 1 << 18), 12, 256), ((20000, 20000), 19, 256),
-                                   ((3000, 200000), 128, 256), ((2048, 1 << 18), 192, 256)):
+                                   ((65536, 65536), 6, 256), ((131072, 65536), 3, 1024), ((32768, 1 << 18), 12, 1024), ((20000, 20000), 19, 256),
+                                   ((65536, 1 << 17), 6, 1024), ((3000, 200000), 128, 256), ((2048, 1 << 18), 192, 256)):   # (1024-row chunks from 16384 rows a worker)
         p, tbl = plan(n, m)
         assert p["workers"] == workers and p["chunk"] == chunk and p["resident"] == 6 and p["lead_rows"] == 0, (n, m, p)
         steps = np.diff(tbl)
