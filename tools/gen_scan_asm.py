@@ -50,7 +50,9 @@ nsub = 16 // G
 
 
 def prologue():
-    return [line(f"s_mov_b64 s[{SP}:{SP + 1}], %[tp]")] + load_set(SA, 0) + [line("Lgroup_%=:")]
+    # (the loop head on a 64-byte boundary: without it the time of a small search moved by 2-5 % with whatever else changed in
+    # the kernel in front of the loop - 2000 x 2000 9.76 / 10.30 us for the same cold loop; profiles/r04_ab_queue.log "fired path")
+    return [line(f"s_mov_b64 s[{SP}:{SP + 1}], %[tp]")] + load_set(SA, 0) + [line(".p2align 6"), line("Lgroup_%=:")]
 
 
 def loads_for(k):
@@ -79,14 +81,28 @@ for k in range(nsub):
 # Eight v_min3_u32 / v_min_u32 instead of a tree of fifteen v_and_b32: min3 can only use the v_bcnt issue slot, but the
 # scan is bound by the OTHER slot (eight v_xor + the filter against eight v_bcnt), so halving the filter's instructions
 # and moving them over measured 1089 -> 1071 us at 64k x 64k, 586 -> 572 us at 32768 x 65536 (profiles/r03_ab_sgpr_feed.log).
-body += [line(f"v_min3_u32 v{VM}, v{ACC}, v{ACC + 1}, v{ACC + 2}")]
-body += [line(f"v_min3_u32 v{VM}, v{VM}, v{ACC + 3 + 2 * i}, v{ACC + 4 + 2 * i}") for i in range(6)]
-body += [line(f"v_min_u32 v{VM}, v{VM}, v{ACC + 15}"), line(f"v_cmp_lt_i32 vcc, -1, v{VM}"), line("s_cbranch_vccz Lnofire_%=")]
-for u in range(16):   # update path: a row whose ballot is empty is skipped (wave-uniform)
-    body += [line(f"v_cmp_lt_i32 vcc, -1, v{ACC + u}"), line(f"s_cbranch_vccz Lskip{u}_%="),
-             line(f"s_add_u32 s{STMP}, %[idx], {u}"), line(f"v_sub_u32 v{VKEY}, v{ACC + u}, %[init]"),
-             line(f"v_lshl_or_b32 v{VKEY}, v{VKEY}, 23, s{STMP}"), line(f"v_med3_u32 %[b2], %[b1], %[b2], v{VKEY}"),
-             line(f"v_min_u32 %[b1], %[b1], v{VKEY}"), line(f"Lskip{u}_%=:")]
+# The minimum is taken as five minima of three rows (into the temporaries, which are free once the group's rows are done), then
+# over those and row 15: eight instructions like a plain chain - but a group that fires finds its rows by testing the five
+# triples first and only the rows of a triple that fired: nine compares where sixteen were for the usual single firing row
+# (a fifth of the groups fire at 64k x 64k: SQ counters, profiles/r04_valu_by_exchange_form.log).
+body += [line(f"v_min3_u32 v{TMP + t}, v{ACC + 3 * t}, v{ACC + 3 * t + 1}, v{ACC + 3 * t + 2}") for t in range(5)]
+body += [line(f"v_min3_u32 v{VM}, v{TMP}, v{TMP + 1}, v{TMP + 2}"), line(f"v_min3_u32 v{VM}, v{VM}, v{TMP + 3}, v{TMP + 4}"),
+         line(f"v_min_u32 v{VM}, v{VM}, v{ACC + 15}"), line(f"v_cmp_lt_i32 vcc, -1, v{VM}"), line("s_cbranch_vccz Lnofire_%=")]
+
+
+def fired_row(u):   # update path of one row: skipped when its ballot is empty (wave-uniform)
+    return [line(f"v_cmp_lt_i32 vcc, -1, v{ACC + u}"), line(f"s_cbranch_vccz Lskip{u}_%="),
+            line(f"s_add_u32 s{STMP}, %[idx], {u}"), line(f"v_sub_u32 v{VKEY}, v{ACC + u}, %[init]"),
+            line(f"v_lshl_or_b32 v{VKEY}, v{VKEY}, 23, s{STMP}"), line(f"v_med3_u32 %[b2], %[b1], %[b2], v{VKEY}"),
+            line(f"v_min_u32 %[b1], %[b1], v{VKEY}"), line(f"Lskip{u}_%=:")]
+
+
+for t in range(5):
+    body += [line(f"v_cmp_lt_i32 vcc, -1, v{TMP + t}"), line(f"s_cbranch_vccz Ltriple{t}_%=")]
+    for u in range(3 * t, 3 * t + 3):
+        body += fired_row(u)
+    body += [line(f"Ltriple{t}_%=:")]
+body += fired_row(15)
 body += [line(f"v_lshrrev_b32 v{VKEY}, 23, %[b2]"), line(f"v_sub_u32 v{VKEY}, 0x80000000, v{VKEY}"),
          line(f"v_max_u32 %[init], %[init], v{VKEY}"), line("Lnofire_%=:")] + epilogue()
 
@@ -144,8 +160,8 @@ text = f'''// bf_scan_sgpr.h - GENERATED by tools/gen_scan_asm.py; edit the gene
 // sits in front of those loads.  The last sub-group of a group loads the next group's first rows unless the call ends
 // there: nothing is read past the requested rows.
 // Per row: s_setprio 0, eight v_xor (SGPR train word -> temporary), s_setprio 2, eight accumulating v_bcnt (row_acc in
-// bf_hamming.hip explains the priorities).  Per group: the unsigned minimum of the sixteen accumulators (min3 chain), one compare, one branch; the
-// update block (unlikely) tests each row's ballot and folds a fired row into (b1, b2) by med3 / min on the packed keys
+// bf_hamming.hip explains the priorities).  Per group: the unsigned minimum of the sixteen accumulators (five minima of three rows, then over those), one compare, one branch; the
+// update block (unlikely) tests the five triples' ballots, then each row's of a triple that fired, and folds a fired row into (b1, b2) by med3 / min on the packed keys
 // (distance << 23 | train index), then tightens the threshold: the arithmetic of filter_update, bit for bit.
 #pragma once
 #define SLAM_SCAN_GROUPS_ASM(Q_, TP_, NG_, IDX_, B1_, B2_, INIT_) \\
