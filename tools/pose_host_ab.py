@@ -1,6 +1,12 @@
-import os, sys, time, ctypes
+"""The pose-only refinement on host buffers (slam_pose_optimize_host_f64), microseconds per call at 50 / 200 / 500 edges, for the
+shipped library or another build (SLAM_LIB=tools/exp/libslamhip_X.so).  Development aid.    python tools/pose_host_ab.py"""
+import os
+import sys
+import time
+
 import numpy as np
-ROOT="/root/repo"
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "slam-experiments_amd"))
 from slamhip import _lib
 if os.environ.get("SLAM_LIB"): _lib.LIB_PATH=os.path.abspath(os.environ["SLAM_LIB"])
