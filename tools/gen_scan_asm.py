@@ -86,8 +86,20 @@ for k in range(nsub):
 # triples first and only the rows of a triple that fired: nine compares where sixteen were for the usual single firing row
 # (a fifth of the groups fire at 64k x 64k: SQ counters, profiles/r04_valu_by_exchange_form.log).
 body += [line(f"v_min3_u32 v{TMP + t}, v{ACC + 3 * t}, v{ACC + 3 * t + 1}, v{ACC + 3 * t + 2}") for t in range(5)]
-body += [line(f"v_min3_u32 v{VM}, v{TMP}, v{TMP + 1}, v{TMP + 2}"), line(f"v_min3_u32 v{VM}, v{VM}, v{TMP + 3}, v{TMP + 4}"),
-         line(f"v_min_u32 v{VM}, v{VM}, v{ACC + 15}"), line(f"v_cmp_lt_i32 vcc, -1, v{VM}"), line("s_cbranch_vccz Lnofire_%=")]
+MINFORM = os.environ.get("SLAM_SCAN_MINFORM", "8min")    # experiment: how the five triple minima and row 15 are combined
+if MINFORM == "8min":        # three more minima: every instruction of the group test in the v_bcnt issue slot
+    body += [line(f"v_min3_u32 v{VM}, v{TMP}, v{TMP + 1}, v{TMP + 2}"), line(f"v_min3_u32 v{VM}, v{VM}, v{TMP + 3}, v{TMP + 4}"),
+             line(f"v_min_u32 v{VM}, v{VM}, v{ACC + 15}")]
+elif MINFORM == "5min5and":  # only the sign bits matter: v_and_b32 on VGPRs can use either issue slot
+    body += [line(f"v_and_b32 v{VM}, v{TMP}, v{TMP + 1}"), line(f"v_and_b32 v{TMP + 5}, v{TMP + 2}, v{TMP + 3}"),
+             line(f"v_and_b32 v{VM}, v{VM}, v{TMP + 5}"), line(f"v_and_b32 v{TMP + 5}, v{TMP + 4}, v{ACC + 15}"),
+             line(f"v_and_b32 v{VM}, v{VM}, v{TMP + 5}")]
+elif MINFORM == "6min3and":
+    body += [line(f"v_min3_u32 v{TMP + 5}, v{TMP + 3}, v{TMP + 4}, v{ACC + 15}"), line(f"v_and_b32 v{VM}, v{TMP}, v{TMP + 1}"),
+             line(f"v_and_b32 v{TMP + 5}, v{TMP + 2}, v{TMP + 5}"), line(f"v_and_b32 v{VM}, v{VM}, v{TMP + 5}")]
+else:
+    raise SystemExit(f"unknown SLAM_SCAN_MINFORM {MINFORM}")
+body += [line(f"v_cmp_lt_i32 vcc, -1, v{VM}"), line("s_cbranch_vccz Lnofire_%=")]
 
 
 def fired_row(u):   # update path of one row: skipped when its ballot is empty (wave-uniform)
