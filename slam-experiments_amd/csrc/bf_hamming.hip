@@ -1029,7 +1029,11 @@ static bf_plan make_plan_core(int num_cu, const int* k, int64_t N, int64_t M, st
     p.cold = k[6] < 0 ? 0 : (k[6] ? k[6] : SLAM_COLD_ROWS);
     if (k[6] == 0 && lead_rows == 0 && M < 16384 && p.chunk <= 384 && p.cold < p.chunk) p.cold = (p.chunk + 15) / 16 * 16;
     const bool short_chunks = p.chunk <= p.cold && lead_rows == 0 && !rows_on_host;
-    p.sfeed = p.R == 1 && (k[5] == 1 || (k[5] == 0 && (p.chunk >= 2 * SLAM_TILE_ROWS || short_chunks))) ? 1 : 0;
+    // Since the scan's fired groups go by triples (round 4, second half) the SGPR form is at least as fast wherever the rows lie in
+    // device memory - also on the one-tile chunks of the leader regime that stayed on the LDS tile until then (2048 x 40000 45.7 ->
+    // 34.3 us, 200 x 20000 21.2 -> 17.9, 64 x 65536 27.0 -> 24.1, 8192 x 16384 50.5 -> 48.4; profiles/r04_ab_queue.log "feed"):
+    // the LDS tile is left for rows in pinned host memory and for several queries per lane.
+    p.sfeed = p.R == 1 && (k[5] == 1 || (k[5] == 0 && (p.chunk >= 2 * SLAM_TILE_ROWS || short_chunks || !rows_on_host))) ? 1 : 0;
     p.uni = p.tail == 0 && p.lead == 0 ? p.chunk : 0;
     // one round and no chunk longer than the unfiltered start: the kernel exchanges no bounds at all (passed as -cold)
     if (qb_launch * (int64_t)p.S <= slots && p.chunk <= p.cold && p.lead == 0) p.cold = -p.cold;   // (S: the tail's extra chunks counted)

@@ -115,12 +115,14 @@ def test_shipped_rules_on_a_256_cu_device(plan):
     assert not p["table_free"] and not p["bound_free"] and p["cold_rows"] == 128
     p, _ = plan(65536, 65536, queue=-1)
     assert not p["table_free"] and not p["bound_free"] and p["chunk"] == 4096 and p["lead_chunks"] == 1 and p["chunks"] == 19   # 16 blocks per CU
-    # the feed: SGPRs for chunks of >= 512 rows and for chunks inside the unfiltered start, the LDS tile in between -
-    # and always for rows that lie in pinned host memory unless the chunks are long (those rows were copied to the device)
+    # the feed: SGPRs wherever the rows lie in device memory (since round 4 also on the leader regime's one-tile chunks); the LDS
+    # tile for rows in pinned host memory unless the chunks are long, and for several queries per lane
     assert plan(65536, 65536)[0]["sgpr_feed"] == 1 and plan(8192, 65536)[0]["sgpr_feed"] == 1
     assert plan(4096, 4096)[0]["sgpr_feed"] == 1 and plan(200, 200)[0]["sgpr_feed"] == 1
     assert plan(8192, 8192)[0]["sgpr_feed"] == 1 and plan(12000, 12000)[0]["sgpr_feed"] == 1
-    assert plan(5000, 20000, chunk=256, lead_rows=-1)[0]["sgpr_feed"] == 0           # a filtered one-tile chunk: the LDS tile
+    assert plan(5000, 20000, chunk=256, lead_rows=-1)[0]["sgpr_feed"] == 1 and plan(200, 20000)[0]["sgpr_feed"] == 1
+    assert plan(2048, 40000)[0]["sgpr_feed"] == 1 and plan(5000, 20000, feed=-1)[0]["sgpr_feed"] == 0 and plan(5000, 20000, R=2)[0]["sgpr_feed"] == 0
+    assert plan(3000, 20000, rows_on_host=True)[0]["sgpr_feed"] == 0                # rows in pinned host memory: the LDS tile
     assert plan(4096, 4096, rows_on_host=True)[0]["sgpr_feed"] == 0 and plan(200, 200, rows_on_host=True)[0]["sgpr_feed"] == 0
     # no more query blocks than CUs: 16 blocks per CU and up to 32 shrinking chunks at the end (the 1/8 shard of the headline
     # grid); more query blocks than CUs: 32 blocks per CU
