@@ -384,6 +384,18 @@ __device__ __forceinline__ void bf_top2_block(const uint4* __restrict__ q, int N
         for (int r = 0; r < R; r++) init[r] = max(init[r], SLAM_ACC_BIAS - (b2[r] >> SLAM_KEY_IDX_BITS));
     };
 
+    // What the epilogue needs of the kernel arguments, parked in VECTOR registers in front of the scan: the SGPR-fed scan statement
+    // clobbers two thirds of the SGPRs, so the compiler would fetch N, the grid's height and the result pointers again from the
+    // argument segment behind it - scalar loads on the hand-off's critical path whose lines the scan's row stream has pushed out of
+    // the scalar cache by then (200 x 1000: 7.2 us against 6.3 in round 3, whose kernel had fewer arguments; profiles/
+    // r04_ab_queue.log "parked arguments").  Every use below is a per-lane compare or address, so vector registers serve as they are.
+    int N_e = N, S_e = S, base_e = train_base;
+    int2* oi_e = out_idx;
+    int2* od_e = out_dist;
+    if constexpr (SFEED) {
+        asm volatile("" : "+v"(N_e), "+v"(S_e), "+v"(base_e));
+        asm volatile("" : "+v"(oi_e), "+v"(od_e));
+    }
     // uni > 0: the plan is `uni` rows per chunk throughout (single-round launches: frame-sized searches and everything up
     // to a few thousand rows a side) - no boundary table to read, and none to upload in front of the launch
     if constexpr (SFEED) {
@@ -611,7 +623,7 @@ __device__ __forceinline__ void bf_top2_block(const uint4* __restrict__ q, int N
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const int qi = qbase + r * 64;
-        if (qi < N && b1[r] != SLAM_KEY_NONE && (b1[r] >> SLAM_KEY_IDX_BITS) <= gk[r] &&
+        if (qi < N_e && b1[r] != SLAM_KEY_NONE && (b1[r] >> SLAM_KEY_IDX_BITS) <= gk[r] &&
             (b2[r] != pend[r] || b2[r] == SLAM_KEY_NONE)) {       // (a lone row: b2 is none, and so was it at the last fold)
             u32* half = (u32*)&st.best[qi];
             const u32 o1 = atomicMin(half + 1, b1[r]);
@@ -629,7 +641,7 @@ __device__ __forceinline__ void bf_top2_block(const uint4* __restrict__ q, int N
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const int qi = qbase + r * 64;
-        if (qi < N && b1[r] != SLAM_KEY_NONE && (b1[r] >> SLAM_KEY_IDX_BITS) <= gk[r]) {
+        if (qi < N_e && b1[r] != SLAM_KEY_NONE && (b1[r] >> SLAM_KEY_IDX_BITS) <= gk[r]) {
             u32* half = (u32*)&st.best[qi];                       // little endian: [0] = 2nd key, [1] = 1st key
             const u32 o1 = atomicMin(half + 1, b1[r]);
             const u32 push = min(max(o1, b1[r]), b2[r]);
@@ -682,7 +694,7 @@ __device__ __forceinline__ void bf_top2_block(const uint4* __restrict__ q, int N
     if (tid == 0) {
         const u32 ticket = __hip_atomic_fetch_add(&st.arrivals[bx], 1u, __ATOMIC_RELAXED,
                                                   __HIP_MEMORY_SCOPE_AGENT);
-        s_last = ticket == (u32)S - 1 ? 1u : 0u;
+        s_last = ticket == (u32)S_e - 1 ? 1u : 0u;
         asm volatile("" ::"s"(ticket));                 // (the ticket is back: its value was just used)
     }
     __syncthreads();
@@ -691,18 +703,18 @@ __device__ __forceinline__ void bf_top2_block(const uint4* __restrict__ q, int N
     for (int r = 0; r < R; r++) {
         const int qi = qbase + r * 64;
         int kept = 0;
-        if (qi < N) {
+        if (qi < N_e) {
             // every contribution was made by an agent-scope atomic; it is taken - and the slot put back to idle for the next
             // launch - by one more (all other blocks are done with these queries)
             const unsigned long long v = __hip_atomic_exchange(&st.best[qi], ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const u32 k1 = (u32)(v >> 32), k2 = (u32)v;
             int2 oi, od;
-            oi.x = k1 == SLAM_KEY_NONE ? SLAM_NO_MATCH_IDX : (int)(k1 & SLAM_KEY_IDX_MASK) + train_base;
+            oi.x = k1 == SLAM_KEY_NONE ? SLAM_NO_MATCH_IDX : (int)(k1 & SLAM_KEY_IDX_MASK) + base_e;
             od.x = k1 == SLAM_KEY_NONE ? SLAM_NO_MATCH_DIST : (int)(k1 >> SLAM_KEY_IDX_BITS);
-            oi.y = k2 == SLAM_KEY_NONE ? SLAM_NO_MATCH_IDX : (int)(k2 & SLAM_KEY_IDX_MASK) + train_base;
+            oi.y = k2 == SLAM_KEY_NONE ? SLAM_NO_MATCH_IDX : (int)(k2 & SLAM_KEY_IDX_MASK) + base_e;
             od.y = k2 == SLAM_KEY_NONE ? SLAM_NO_MATCH_DIST : (int)(k2 >> SLAM_KEY_IDX_BITS);
-            out_idx[qi] = oi;
-            out_dist[qi] = od;
+            oi_e[qi] = oi;
+            od_e[qi] = od;
             if (sel.keep) {
                 // (double) comparisons of integers <= 256: exact, and the same arithmetic as filter_keep_kernel
                 const bool k = oi.x >= 0 && (sel.mode == 0 || (oi.y >= 0 && (double)od.x < sel.param * (double)od.y));
@@ -711,7 +723,7 @@ __device__ __forceinline__ void bf_top2_block(const uint4* __restrict__ q, int N
             }
             if (!merging) __hip_atomic_store(&st.bound[qi], SLAM_BOUND_IDLE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (sel.keep && qi - lane < N) {                   // (wave-uniform: the group's first query exists)
+        if (sel.keep && qi - lane < N_e) {                   // (wave-uniform: the group's first query exists)
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) kept += __shfl_xor(kept, off, 64);
             if (lane == 0) sel.wave_kept[qi >> 6] = kept;
