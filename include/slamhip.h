@@ -149,8 +149,8 @@ SLAM_API int slam_bf_knn2_u256_host(slam_ctx* ctx, const uint8_t* h_query, int64
  *   [4] tail          number of linearly shrinking chunks at the end of the grid (shipped: up to 32, none for grids of
  *                     at most two blocks per CU); -1 = none
  *   [5] feed          how train rows reach the lanes at R = 1: 1 = through SGPRs (scalar loads, no LDS), -1 = through an LDS
- *                     tile (shipped: SGPRs when a chunk has at least 512 rows or is scanned unfiltered throughout and
- *                     its rows are in device memory, the LDS tile otherwise)
+ *                     tile (shipped: SGPRs whenever the rows are in device memory, and for chunks of at least 512 rows; the
+ *                     LDS tile for rows in pinned host memory - the zero-copy frame-sized host calls)
  *   [6] cold          rows a chunk folds in WITHOUT a filter when it starts before anybody has published a bound for its
  *                     queries, a multiple of 16 (shipped: 128, and the whole chunk for train sets below 16384 rows whose
  *                     chunks have at most 384 rows); -1 = none
